@@ -1,0 +1,42 @@
+# Builds the shipped libraries in-tree (rt_amd/lib, rt_amd/bin) and, separately, the test-only checkers.
+#   make            -> librt_hip.so (hipcc, gfx950), librt_host.so + rt_cli (g++)
+#   make checkers   -> oracle/librt_oracle.so and tests/emu/libcore_emu.so (never linked into the above)
+HIPCC    ?= hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Irt_amd/csrc
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -Irt_amd/host
+
+LIB := rt_amd/lib
+BIN := rt_amd/bin
+CORE_HDRS := rt_amd/csrc/rt_core.h rt_amd/csrc/rt_prep.h include/rt_hip.h
+HOST_HDRS := $(wildcard rt_amd/host/*/*.hpp) include/rt_hip.h include/rt_host.h
+
+all: $(LIB)/librt_hip.so $(LIB)/librt_host.so $(BIN)/rt_cli
+
+$(LIB)/librt_hip.so: rt_amd/csrc/rt_hip.hip $(CORE_HDRS)
+	@mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -shared rt_amd/csrc/rt_hip.hip -o $@
+
+$(LIB)/librt_host.so: rt_amd/host/rt_host_capi.cpp rt_amd/host/rt_hip/demo_frame_hip.cpp $(HOST_HDRS) $(LIB)/librt_hip.so
+	$(CXX) $(CXXFLAGS) -shared rt_amd/host/rt_host_capi.cpp rt_amd/host/rt_hip/demo_frame_hip.cpp \
+	    -L$(LIB) -lrt_hip -Wl,-rpath,'$$ORIGIN' -o $@
+
+$(BIN)/rt_cli: rt_amd/host/cli/main.cpp $(HOST_HDRS) $(LIB)/librt_host.so
+	@mkdir -p $(BIN)
+	$(CXX) $(CXXFLAGS) rt_amd/host/cli/main.cpp -L$(LIB) -lrt_host -lrt_hip \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -pthread -o $@
+
+checkers: oracle/librt_oracle.so tests/emu/libcore_emu.so
+
+oracle/librt_oracle.so: oracle/rt_oracle.c oracle/rt_oracle.h
+	$(MAKE) -C oracle
+
+tests/emu/libcore_emu.so: tests/emu/core_emu.cpp $(CORE_HDRS)
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -Irt_amd/csrc tests/emu/core_emu.cpp -o $@
+
+clean:
+	rm -f $(LIB)/*.so $(BIN)/rt_cli tests/emu/libcore_emu.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all checkers clean

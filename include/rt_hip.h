@@ -1,0 +1,170 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X (gfx950) ray-tracing backend for rokuz/rt.
+ *
+ * This is the layer a ray_tracing::Frame subclass binds to, in place of the reference's
+ * namespace ray_tracing_cuda free functions (rt_cuda/rt_cuda.h:16-32).  Plain C: no HIP types, no
+ * C++ types, no exceptions; every call returns an int status (RT_HIP_OK == 0) and leaves a message
+ * for rt_hip_last_error() on failure.  Nothing is printed.
+ *
+ * Conventions
+ *   - Host images are float[height * width * 3], RGB interleaved, row 0 on top, linear radiance
+ *     already divided by samples_in_row^2 -- the memory layout of the reference's ColorBuffer
+ *     (ray_tracing/frame.hpp:21) as DemoFrameCUDA hands it over (rt_cuda/demo_frame_cuda.cpp:39,146).
+ *   - Device sum buffers are float[3 * height * width]: three planes (R, G, B) of un-normalised
+ *     per-pixel sums; rt_hip_resolve_device turns them into the interleaved image.
+ *   - A trace can be restricted to a slice of the sample space: sample s of pixel p belongs to
+ *     slice (s + p) % slice_count.  The sums of all slices add up to the whole frame, which is how
+ *     one frame is sharded over several GPUs (one process per GPU; the caller reduces the planes).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_HIP_OK 0
+#define RT_HIP_ERR_INVALID 1    /* bad argument */
+#define RT_HIP_ERR_DEVICE 2     /* a HIP call failed; see rt_hip_last_error() */
+#define RT_HIP_ERR_NOT_READY 3  /* rt_hip_job_poll: the job is still running */
+#define RT_HIP_ERR_CANCELLED 4  /* the job was cancelled before it finished */
+
+/* Type tags, ray_tracing/types.hpp:12-20. */
+#define RT_HIP_MATERIAL_MATTE 0u
+#define RT_HIP_MATERIAL_METAL 1u
+#define RT_HIP_MATERIAL_GLASS 2u
+#define RT_HIP_LIGHT_DIRECTIONAL 0u
+
+/* Trace flags. */
+#define RT_HIP_FLAG_DETERMINISTIC 1u /* no stochastic scattering: ballRand == 0, glass branch draw == 0.5 */
+
+/* Replaces CudaMaterial (rt_cuda/types_cuda.h): what Material::GetType/GetAlbedo/GetRoughness/
+ * GetRefraction return (ray_tracing/material.hpp:20-26). */
+typedef struct
+{
+  uint32_t type;
+  float albedo[3];
+  float roughness;
+  float refraction;
+} rt_hip_material;
+
+/* Replaces CudaLight (rt_cuda/types_cuda.h): DirectionalLight::GetDirection/GetColor
+ * (ray_tracing/directional_light.hpp:20-21). */
+typedef struct
+{
+  uint32_t type;
+  float direction[3];
+  float color[3];
+} rt_hip_light;
+
+/* The camera/background arguments of ray_tracing_cuda::RayTrace (rt_cuda/rt_cuda.h:21-22);
+ * values as Frame holds them (ray_tracing/frame.hpp:66-72).  direction must be normalised. */
+typedef struct
+{
+  float position[3];
+  float direction[3];
+  float fov;
+  float znear;
+  float zfar;
+  float background[3];
+} rt_hip_camera;
+
+typedef struct
+{
+  uint32_t width;
+  uint32_t height;
+  uint32_t samples_in_row; /* S: S*S samples per pixel, regular grid (ray_tracing/frame.cpp:56-66) */
+  uint32_t flags;          /* RT_HIP_FLAG_* */
+  uint32_t seed;           /* Philox key word: key = (pixel, sample ^ seed), counter = (bounce, block) */
+  uint32_t max_depth;      /* 0 -> 10 (demos/demo_frame_cpu.cpp:10); 1 = primary hit + direct light only */
+  uint32_t slice_index;    /* see "Conventions" */
+  uint32_t slice_count;    /* 0 or 1 -> the whole sample space */
+} rt_hip_trace_params;
+
+/* Work counters of one trace, counted on the device. */
+typedef struct
+{
+  uint64_t samples;        /* camera samples traced */
+  uint64_t ray_queries;    /* nearest-hit + shadow queries the algorithm asks for, each against all spheres */
+  uint64_t hit_queries;    /* nearest-hit queries that found a hit */
+  uint64_t shaded_bounces; /* hits that ran direct light + specular */
+  uint64_t sphere_tests;   /* ray-sphere tests executed (includes padding lanes and unused scatter rays) */
+  float kernel_ms;         /* device time of the trace kernel(s), HIP events on the launch stream; 0 if not measured */
+  uint32_t reserved;
+} rt_hip_stats;
+
+typedef struct rt_hip_scene rt_hip_scene;
+typedef struct rt_hip_job rt_hip_job;
+
+/* Replaces ray_tracing_cuda::Initialize (rt_cuda/rt_cuda.h:16, rt_cuda/rt_cuda.cu:71-96): selects
+ * the device for this process (one process per GPU).  device < 0 keeps the current device. */
+int rt_hip_init(int device);
+
+/* Releases everything the library still owns on the device. */
+void rt_hip_shutdown(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char * rt_hip_last_error(void);
+
+/* Device facts used for the FP32 vector roofline: peak = cus * 4 SIMDs * 32 lanes * 2 FLOP * clock. */
+int rt_hip_device_info(int * compute_units, int * clock_khz, char * name, size_t name_len);
+
+/* Uploads a flattened scene once; replaces the per-trace cudaMalloc+cudaMemcpy of spheres, materials and
+ * lights in ray_tracing_cuda::RayTrace (rt_cuda/rt_cuda.cu:186-223).  centers_radii = sphere_count x
+ * {cx, cy, cz, radius} (CudaSphere's centre and radius), material_index = sphere_count indices into
+ * materials.  The caller keeps its arrays. */
+int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_index, uint32_t sphere_count,
+                        const rt_hip_material * materials, uint32_t material_count,
+                        const rt_hip_light * lights, uint32_t light_count, rt_hip_scene ** out_scene);
+void rt_hip_scene_destroy(rt_hip_scene * scene);
+
+/* Replaces ray_tracing_cuda::RayTrace (rt_cuda/rt_cuda.h:19-23): enqueues one frame on the library's own
+ * non-blocking stream and returns immediately with a job handle (instead of a cudaEvent_t).  No host
+ * worker thread and no realtimeHandler callback are needed: progress is pulled with rt_hip_job_snapshot. */
+int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                       const rt_hip_trace_params * params, rt_hip_job ** out_job);
+
+/* Replaces ray_tracing_cuda::InProgress (rt_cuda/rt_cuda.h:26): RT_HIP_OK when the frame is complete,
+ * RT_HIP_ERR_NOT_READY while it runs. */
+int rt_hip_job_poll(rt_hip_job * job);
+
+/* Replaces ray_tracing_cuda::CopyOutputToBuffer (rt_cuda/rt_cuda.h:29): copies what has been rendered so
+ * far (unfinished pixels are black) into rgb without stalling the trace. */
+int rt_hip_job_snapshot(rt_hip_job * job, float * rgb);
+
+/* Replaces ray_tracing_cuda::FinishRayTrace (rt_cuda/rt_cuda.h:32): waits for the frame, writes the final
+ * image to rgb (may be NULL), fills stats (may be NULL) and destroys the job. */
+int rt_hip_job_finish(rt_hip_job * job, float * rgb, rt_hip_stats * stats);
+
+/* Replaces the needInterrupt flag returned by the reference's realtimeHandler
+ * (rt_cuda/demo_frame_cuda.cpp:60-65, rt_cuda/rt_cuda.cu:271-275): asks the running kernel to stop
+ * handing out pixels.  The job must still be finished with rt_hip_job_finish. */
+int rt_hip_job_cancel(rt_hip_job * job);
+
+/* Device-resident form of the same frame, for callers that own device memory and a stream (multi-GPU
+ * drivers, benchmarks): traces the requested slice into d_sum_planes (float[3*h*w], device memory, fully
+ * overwritten) on `stream` (a hipStream_t passed as void*; NULL = the default stream), asynchronously.
+ * d_stats (device memory, may be NULL) receives an rt_hip_stats with the counters of this call
+ * (kernel_ms is left 0). */
+int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                        const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
+                        void * stream);
+
+/* The accumulate/resolve pass: d_rgb[p*3+c] = d_sum_planes[c*h*w + p] * (1 / S^2)
+ * (ray_tracing/frame.cpp:43,67), planar sums -> interleaved image, on `stream`. */
+int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t width, uint32_t height,
+                          uint32_t samples_in_row, void * stream);
+
+/* Average device time (ms) of the trace kernel over `launches` back-to-back launches of the given frame on
+ * the library's stream, measured with HIP events on that stream; used by the benchmark's roofline line. */
+int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                             const rt_hip_trace_params * params, uint32_t launches, float * out_avg_ms,
+                             rt_hip_stats * out_stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,51 @@
+/*
+ * rt_host.h -- C entry points of the C++ host library (librt_host), for scripts and tests.
+ *
+ * The host library holds the C++ side of the drop-in: the object model and Frame plug-in API of the
+ * reference (ray_tracing/frame.hpp:24-73), DemoFrameHIP (the Frame that binds librt_hip) and the demo
+ * scenes.  These functions expose what a script needs from it: the flattened demo scenes, a render of a
+ * demo through the Frame API, and the viewer's float -> RGBA8 conversion.  They have no counterpart in
+ * the reference, which has no scripting interface.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Demo indices follow the reference's -d flag (main.cpp:74,85-92): 1 = pretty spheres, 2 = glass spheres;
+ * 3 = synthetic sphere field (not in the reference). */
+#define RT_HOST_DEMO_PRETTY 1u
+#define RT_HOST_DEMO_GLASS 2u
+#define RT_HOST_DEMO_SYNTHETIC 3u
+
+typedef struct rt_host_scene rt_host_scene;
+
+/* Builds demo `demo` from `seed` (synthetic_spheres is used by demo 3 only) and flattens it exactly as
+ * DemoFrameHIP does before upload.  No device is touched. */
+int rt_host_scene_build(uint32_t demo, uint32_t seed, uint32_t synthetic_spheres, rt_host_scene ** out);
+void rt_host_scene_counts(const rt_host_scene * scene, uint32_t * spheres, uint32_t * materials,
+                          uint32_t * lights);
+/* Copies the arrays out; each destination must hold the counts reported above (any may be NULL). */
+void rt_host_scene_copy(const rt_host_scene * scene, float * centers_radii, uint32_t * material_index,
+                        rt_hip_material * materials, rt_hip_light * lights, rt_hip_camera * camera);
+void rt_host_scene_free(rt_host_scene * scene);
+
+/* Renders a demo through the Frame plug-in API on DemoFrameHIP, the way the reference's App drives a
+ * frame (app.cpp:61-109): Initialize, TraceAllRays, poll HasFinished.  params gives width, height,
+ * samples_in_row, flags, seed (render seed), max_depth and the sample slice; scene_seed seeds the scene.
+ * rgb = width*height*3 floats.  On failure returns non-zero and writes a message to err. */
+int rt_host_render_demo(uint32_t demo, uint32_t scene_seed, uint32_t synthetic_spheres,
+                        const rt_hip_trace_params * params, float * rgb, rt_hip_stats * stats, char * err,
+                        size_t err_len);
+
+/* App::UpdateTexture (app.cpp:128-138): rgba[i*4+c] = (uint8)(255 * clamp(rgb[i*3+c], 0, 1)), alpha 255. */
+void rt_host_update_texture(const float * rgb, size_t pixels, uint8_t * rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

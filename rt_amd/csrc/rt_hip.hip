@@ -1,0 +1,731 @@
+// rt_hip.hip -- gfx950 kernels and the C ABI of the MI355X ray-tracing backend (include/rt_hip.h).
+//
+// Kernels
+//   trace_kernel<false>  persistent waves; the whole scene (<= kTileSpheres spheres) sits in LDS for the
+//                        life of the block; every lane runs the path state machine of rt_core.h and pulls
+//                        pixels from one frame-wide atomic counter, 64 lanes per atomic (ballot + prefix
+//                        count).  Waves never wait for each other.
+//   trace_kernel<true>   the same loop for larger scenes: the block re-stages the spheres through LDS in
+//                        tiles of kTileSpheres inside every ray pass, so its waves stay in step.
+//   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
+//                        16 bytes per lane per access; the only HBM-bound pass.
+//
+// LDS per block: 10 x float4 path stack per lane (40 KB at 256 lanes) + the sphere tile (16 B per sphere).
+#include "rt_core.h"
+#include "rt_hip.h"
+#include "rt_prep.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace
+{
+using namespace rtc;
+
+constexpr int kBlock = 256;               // 4 waves
+constexpr uint32_t kTileSpheres = 2048;   // 32 KB of LDS per tile
+constexpr uint32_t kStatsWords = 5;
+
+// ---------------------------------------------------------------- device side
+
+struct WaveEnv
+{
+  const TraceArgs & A;
+  const f4 * sph;  // LDS: the whole scene
+  uint32_t total_pixels;
+
+  __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+
+  // One atomic per wave hands consecutive pixels to the lanes that asked.
+  __device__ __forceinline__ uint32_t fetch_pixel(bool need) const
+  {
+    unsigned long long const mask = __ballot(need);
+    uint32_t const lane = __lane_id();
+    int const leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (need && (int)lane == leader)
+      base = atomicAdd(A.queue_counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t const p = base + rank;
+    return (need && p < total_pixels) ? p : RT_INVALID;
+  }
+
+  __device__ __forceinline__ f4 sphere(int i) const { return sph[i]; }
+  __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+
+  __device__ __forceinline__ void run_pass(f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
+                                           const float (&tlo_a)[RT_RAYS], float (&best)[RT_RAYS],
+                                           int (&idx)[RT_RAYS]) const
+  {
+    ray_pass(sph, A.n_spheres, 0u, o, dir, a, tlo_a, best, idx);
+  }
+};
+
+struct BlockEnv
+{
+  const TraceArgs & A;
+  f4 * tile;  // LDS: kTileSpheres entries
+  uint32_t total_pixels;
+
+  // The block's waves share the staging barriers inside run_pass, so every loop decision is block-wide.
+  __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
+
+  __device__ __forceinline__ uint32_t fetch_pixel(bool need) const
+  {
+    unsigned long long const mask = __ballot(need);
+    uint32_t const lane = __lane_id();
+    int const leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (need && (int)lane == leader)
+      base = atomicAdd(A.queue_counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t const p = base + rank;
+    return (need && p < total_pixels) ? p : RT_INVALID;
+  }
+
+  __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
+  __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+
+  __device__ __forceinline__ void run_pass(f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
+                                           const float (&tlo_a)[RT_RAYS], float (&best)[RT_RAYS],
+                                           int (&idx)[RT_RAYS]) const
+  {
+    for (uint32_t base = 0; base < A.n_spheres; base += kTileSpheres)
+    {
+      uint32_t const count = min(kTileSpheres, A.n_spheres - base);
+      __syncthreads();  // everyone is done with the previous tile
+      for (uint32_t i = threadIdx.x; i < count; i += kBlock)
+        tile[i] = A.spheres[base + i];
+      __syncthreads();
+      ray_pass(tile, count, base, o, dir, a, tlo_a, best, idx);
+    }
+  }
+};
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off);
+  return v;
+}
+
+template <bool kTiled>
+__global__ __launch_bounds__(kBlock, 2) void trace_kernel(TraceArgs A)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  f4 * stack = reinterpret_cast<f4 *>(lds_raw);                  // [RT_MAX_DEPTH][kBlock]
+  f4 * sph = stack + RT_MAX_DEPTH * kBlock;                      // sphere tile
+  uint32_t const total_pixels = A.width * A.height;
+
+  LaneCounters cnt = {0u, 0u, 0u, 0u, 0u};
+  if constexpr (kTiled)
+  {
+    BlockEnv env{A, sph, total_pixels};
+    trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+  }
+  else
+  {
+    for (uint32_t i = threadIdx.x; i < A.n_spheres; i += kBlock)
+      sph[i] = A.spheres[i];
+    __syncthreads();
+    WaveEnv env{A, sph, total_pixels};
+    trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+  }
+
+  // Work counters: one 64-bit atomic per wave and counter.
+  uint32_t const samples = wave_sum(cnt.samples);
+  uint32_t const queries = wave_sum(cnt.queries);
+  uint32_t const hits = wave_sum(cnt.hits);
+  uint32_t const shaded = wave_sum(cnt.shaded);
+  uint32_t const passes = wave_sum(cnt.passes);
+  if (A.stats != nullptr && __lane_id() == 0)
+  {
+    atomicAdd(&A.stats[0], (unsigned long long)samples);
+    atomicAdd(&A.stats[1], (unsigned long long)queries);
+    atomicAdd(&A.stats[2], (unsigned long long)hits);
+    atomicAdd(&A.stats[3], (unsigned long long)shaded);
+    atomicAdd(&A.stats[4], (unsigned long long)passes * (unsigned long long)(RT_RAYS * A.n_spheres));
+  }
+}
+
+// planes: 3 x n floats; rgb: n x 3 floats.  Each lane takes 4 pixels: three 16-byte loads, three 16-byte
+// stores (48 contiguous bytes), so both sides stream in full lines.
+__global__ __launch_bounds__(256) void resolve_kernel(const float * __restrict__ planes,
+                                                      float * __restrict__ rgb, uint32_t n, float inv)
+{
+  uint32_t const quads = n / 4u;
+  uint32_t const stride = gridDim.x * blockDim.x;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride)
+  {
+    float4 const r = reinterpret_cast<const float4 *>(planes)[q];
+    float4 const g = reinterpret_cast<const float4 *>(planes + n)[q];
+    float4 const b = reinterpret_cast<const float4 *>(planes + 2u * (size_t)n)[q];
+    float4 * out = reinterpret_cast<float4 *>(rgb + 12u * (size_t)q);
+    out[0] = make_float4(r.x * inv, g.x * inv, b.x * inv, r.y * inv);
+    out[1] = make_float4(g.y * inv, b.y * inv, r.z * inv, g.z * inv);
+    out[2] = make_float4(b.z * inv, r.w * inv, g.w * inv, b.w * inv);
+  }
+  // tail (n not a multiple of 4)
+  uint32_t const t = quads * 4u + blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n)
+  {
+    rgb[3u * (size_t)t + 0] = planes[t] * inv;
+    rgb[3u * (size_t)t + 1] = planes[n + t] * inv;
+    rgb[3u * (size_t)t + 2] = planes[2u * (size_t)n + t] * inv;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+
+thread_local std::string g_error;
+
+int fail(int code, const char * what, hipError_t e = hipSuccess)
+{
+  g_error = what;
+  if (e != hipSuccess)
+  {
+    g_error += ": ";
+    g_error += hipGetErrorString(e);
+  }
+  return code;
+}
+
+#define RT_CHECK(call)                                         \
+  do                                                           \
+  {                                                            \
+    hipError_t const e_ = (call);                              \
+    if (e_ != hipSuccess)                                      \
+      return fail(RT_HIP_ERR_DEVICE, #call, e_);               \
+  } while (0)
+
+struct Library
+{
+  std::mutex mutex;
+  bool ready = false;
+  int device = 0;
+  int compute_units = 0;
+  int clock_khz = 0;
+  char name[256] = {0};
+  hipStream_t stream = nullptr;       // trace launches of the job API
+  hipStream_t copy_stream = nullptr;  // snapshots, so they never queue behind a running trace
+};
+Library g_lib;
+
+}  // namespace
+
+struct rt_hip_scene
+{
+  f4 * d_spheres = nullptr;
+  uint32_t * d_sphere_mat = nullptr;
+  f4 * d_materials = nullptr;
+  f4 * d_lights = nullptr;
+  uint32_t n_spheres = 0, n_materials = 0, n_lights = 0;
+};
+
+struct rt_hip_job
+{
+  TraceArgs args;
+  rt_hip_trace_params params;
+  float * d_planes = nullptr;
+  float * d_rgb = nullptr;
+  unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
+  hipEvent_t start = nullptr, stop = nullptr;
+  bool cancelled = false;
+};
+
+namespace
+{
+size_t lds_bytes(uint32_t n_spheres)
+{
+  uint32_t const tile = std::min(n_spheres, kTileSpheres);
+  return sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock + std::max(tile, 1u));
+}
+
+// Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
+// more lanes than pixels.
+int persistent_blocks(uint32_t n_spheres, uint32_t pixels, bool tiled)
+{
+  int per_cu = 0;
+  hipError_t e;
+  if (tiled)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true>, kBlock, lds_bytes(n_spheres));
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false>, kBlock, lds_bytes(n_spheres));
+  if (e != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  long long blocks = (long long)per_cu * std::max(g_lib.compute_units, 1);
+  long long const needed = ((long long)pixels + kBlock - 1) / kBlock;
+  blocks = std::max(1ll, std::min(blocks, needed));
+  return (int)blocks;
+}
+
+int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p)
+{
+  if (!g_lib.ready)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_init has not been called");
+  if (scene == nullptr || camera == nullptr || p == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  if (p->width == 0 || p->height == 0 || p->samples_in_row == 0)
+    return fail(RT_HIP_ERR_INVALID, "width, height and samples_in_row must be positive");
+  if ((unsigned long long)p->width * p->height > 0x40000000ull)
+    return fail(RT_HIP_ERR_INVALID, "frame larger than 2^30 pixels");
+  if (p->samples_in_row > 4096u)
+    return fail(RT_HIP_ERR_INVALID, "samples_in_row larger than 4096");
+  if (p->slice_count > 1u && p->slice_index >= p->slice_count)
+    return fail(RT_HIP_ERR_INVALID, "slice_index must be below slice_count");
+  return RT_HIP_OK;
+}
+
+// Enqueues counter reset + trace kernel on `stream`.  d_stats points at kStatsWords counters followed by
+// the queue counter (one 8-byte slot).
+int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
+                 float * d_planes, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
+                 TraceArgs * out_args)
+{
+  TraceArgs a;
+  std::memset(&a, 0, sizeof(a));
+  prepare_frame(*camera, *p, a);
+  a.spheres = scene->d_spheres;
+  a.sphere_mat = scene->d_sphere_mat;
+  a.materials = scene->d_materials;
+  a.lights = scene->d_lights;
+  a.n_spheres = scene->n_spheres;
+  a.n_materials = scene->n_materials;
+  a.n_lights = scene->n_lights;
+  a.planes = d_planes;
+  a.stats = want_stats ? d_stats : nullptr;
+  a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
+  if (out_args)
+    *out_args = a;
+
+  RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
+  bool const tiled = scene->n_spheres > kTileSpheres;
+  uint32_t const pixels = p->width * p->height;
+  int const blocks = persistent_blocks(scene->n_spheres, pixels, tiled);
+  size_t const lds = lds_bytes(scene->n_spheres);
+  if (tiled)
+    hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, a);
+  else
+    hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, a);
+  RT_CHECK(hipGetLastError());
+  return RT_HIP_OK;
+}
+
+int launch_resolve(const float * d_planes, float * d_rgb, uint32_t width, uint32_t height, uint32_t s_row,
+                   hipStream_t stream)
+{
+  uint32_t const n = width * height;
+  float const inv = 1.0f / static_cast<float>(s_row * s_row);  // frame.cpp:43
+  uint32_t const quads = std::max(n / 4u, 1u);
+  int const blocks = (int)std::min<uint32_t>((quads + 255u) / 256u, 256u * 8u);
+  hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, stream, d_planes, d_rgb, n, inv);
+  RT_CHECK(hipGetLastError());
+  return RT_HIP_OK;
+}
+
+void read_stats(const unsigned long long * h, rt_hip_stats * out)
+{
+  out->samples = h[0];
+  out->ray_queries = h[1];
+  out->hit_queries = h[2];
+  out->shaded_bounces = h[3];
+  out->sphere_tests = h[4];
+}
+
+void free_job(rt_hip_job * job)
+{
+  if (job == nullptr)
+    return;
+  if (job->d_planes) (void)hipFree(job->d_planes);
+  if (job->d_rgb) (void)hipFree(job->d_rgb);
+  if (job->d_stats) (void)hipFree(job->d_stats);
+  if (job->start) (void)hipEventDestroy(job->start);
+  if (job->stop) (void)hipEventDestroy(job->stop);
+  delete job;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_hip_init(int device)
+{
+  std::lock_guard<std::mutex> lock(g_lib.mutex);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(RT_HIP_ERR_DEVICE, "no HIP device available", e);
+  if (device >= 0)
+  {
+    if (device >= count)
+      return fail(RT_HIP_ERR_INVALID, "device index out of range");
+    RT_CHECK(hipSetDevice(device));
+  }
+  int current = 0;
+  RT_CHECK(hipGetDevice(&current));
+  if (g_lib.ready && g_lib.device == current)
+    return RT_HIP_OK;
+  if (g_lib.ready)
+  {
+    (void)hipStreamDestroy(g_lib.stream);
+    (void)hipStreamDestroy(g_lib.copy_stream);
+    g_lib.ready = false;
+  }
+  hipDeviceProp_t prop;
+  RT_CHECK(hipGetDeviceProperties(&prop, current));
+  g_lib.device = current;
+  g_lib.compute_units = prop.multiProcessorCount;
+  g_lib.clock_khz = prop.clockRate;
+  std::snprintf(g_lib.name, sizeof(g_lib.name), "%s (%s)", prop.name, prop.gcnArchName);
+  RT_CHECK(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
+  RT_CHECK(hipStreamCreateWithFlags(&g_lib.copy_stream, hipStreamNonBlocking));
+  g_lib.ready = true;
+  return RT_HIP_OK;
+}
+
+void rt_hip_shutdown(void)
+{
+  std::lock_guard<std::mutex> lock(g_lib.mutex);
+  if (!g_lib.ready)
+    return;
+  (void)hipStreamSynchronize(g_lib.stream);
+  (void)hipStreamSynchronize(g_lib.copy_stream);
+  (void)hipStreamDestroy(g_lib.stream);
+  (void)hipStreamDestroy(g_lib.copy_stream);
+  g_lib.stream = nullptr;
+  g_lib.copy_stream = nullptr;
+  g_lib.ready = false;
+}
+
+const char * rt_hip_last_error(void) { return g_error.c_str(); }
+
+int rt_hip_device_info(int * compute_units, int * clock_khz, char * name, size_t name_len)
+{
+  if (!g_lib.ready)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_init has not been called");
+  if (compute_units) *compute_units = g_lib.compute_units;
+  if (clock_khz) *clock_khz = g_lib.clock_khz;
+  if (name && name_len)
+    std::snprintf(name, name_len, "%s", g_lib.name);
+  return RT_HIP_OK;
+}
+
+int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_index, uint32_t sphere_count,
+                        const rt_hip_material * materials, uint32_t material_count,
+                        const rt_hip_light * lights, uint32_t light_count, rt_hip_scene ** out_scene)
+{
+  if (out_scene == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  *out_scene = nullptr;
+  if (!g_lib.ready)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_init has not been called");
+  if ((sphere_count && (!centers_radii || !material_index)) || (material_count && !materials) ||
+      (light_count && !lights))
+    return fail(RT_HIP_ERR_INVALID, "null array with a non-zero count");
+  if (sphere_count > (1u << 24))
+    return fail(RT_HIP_ERR_INVALID, "more than 2^24 spheres");
+  for (uint32_t i = 0; i < sphere_count; ++i)
+    if (material_index[i] >= material_count)
+      return fail(RT_HIP_ERR_INVALID, "material index out of range");
+  for (uint32_t i = 0; i < material_count; ++i)
+    if (materials[i].type > RT_HIP_MATERIAL_GLASS)
+      return fail(RT_HIP_ERR_INVALID, "unknown material type");
+  for (uint32_t i = 0; i < light_count; ++i)
+    if (lights[i].type != RT_HIP_LIGHT_DIRECTIONAL)
+      return fail(RT_HIP_ERR_INVALID, "unknown light type");
+
+  FlatScene fs;
+  flatten_scene(centers_radii, material_index, sphere_count, materials, material_count, lights, light_count, fs);
+
+  rt_hip_scene * s = new (std::nothrow) rt_hip_scene;
+  if (s == nullptr)
+    return fail(RT_HIP_ERR_DEVICE, "out of host memory");
+  s->n_spheres = sphere_count;
+  s->n_materials = material_count;
+  s->n_lights = light_count;
+  auto upload = [](void ** dst, const void * src, size_t bytes) -> hipError_t {
+    // Never a zero-byte allocation: keep the pointer valid for empty arrays.
+    hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+    if (e == hipSuccess && bytes)
+      e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  hipError_t e = upload((void **)&s->d_spheres, fs.spheres.data(), fs.spheres.size() * sizeof(f4));
+  if (e == hipSuccess)
+    e = upload((void **)&s->d_sphere_mat, fs.sphere_mat.data(), fs.sphere_mat.size() * sizeof(uint32_t));
+  if (e == hipSuccess)
+    e = upload((void **)&s->d_materials, fs.materials.data(), fs.materials.size() * sizeof(f4));
+  if (e == hipSuccess)
+    e = upload((void **)&s->d_lights, fs.lights.data(), fs.lights.size() * sizeof(f4));
+  if (e != hipSuccess)
+  {
+    rt_hip_scene_destroy(s);
+    return fail(RT_HIP_ERR_DEVICE, "scene upload", e);
+  }
+  *out_scene = s;
+  return RT_HIP_OK;
+}
+
+void rt_hip_scene_destroy(rt_hip_scene * scene)
+{
+  if (scene == nullptr)
+    return;
+  if (scene->d_spheres) (void)hipFree(scene->d_spheres);
+  if (scene->d_sphere_mat) (void)hipFree(scene->d_sphere_mat);
+  if (scene->d_materials) (void)hipFree(scene->d_materials);
+  if (scene->d_lights) (void)hipFree(scene->d_lights);
+  delete scene;
+}
+
+int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                       const rt_hip_trace_params * params, rt_hip_job ** out_job)
+{
+  if (out_job == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  *out_job = nullptr;
+  int rc = validate(scene, camera, params);
+  if (rc != RT_HIP_OK)
+    return rc;
+
+  rt_hip_job * job = new (std::nothrow) rt_hip_job;
+  if (job == nullptr)
+    return fail(RT_HIP_ERR_DEVICE, "out of host memory");
+  job->params = *params;
+  size_t const pixels = (size_t)params->width * params->height;
+  hipError_t e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_rgb, 3 * pixels * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
+  if (e == hipSuccess) e = hipEventCreate(&job->start);
+  if (e == hipSuccess) e = hipEventCreate(&job->stop);
+  // Unfinished pixels read as black in snapshots.
+  if (e == hipSuccess) e = hipMemsetAsync(job->d_planes, 0, 3 * pixels * sizeof(float), g_lib.stream);
+  if (e == hipSuccess) e = hipEventRecord(job->start, g_lib.stream);
+  if (e != hipSuccess)
+  {
+    free_job(job);
+    return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
+  }
+  rc = launch_trace(scene, camera, params, job->d_planes, job->d_stats, true, g_lib.stream, &job->args);
+  if (rc == RT_HIP_OK)
+  {
+    e = hipEventRecord(job->stop, g_lib.stream);
+    if (e != hipSuccess)
+      rc = fail(RT_HIP_ERR_DEVICE, "hipEventRecord", e);
+  }
+  if (rc != RT_HIP_OK)
+  {
+    (void)hipStreamSynchronize(g_lib.stream);
+    free_job(job);
+    return rc;
+  }
+  *out_job = job;
+  return RT_HIP_OK;
+}
+
+int rt_hip_job_poll(rt_hip_job * job)
+{
+  if (job == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null job");
+  hipError_t const e = hipEventQuery(job->stop);
+  if (e == hipSuccess)
+    return RT_HIP_OK;
+  if (e == hipErrorNotReady)
+    return RT_HIP_ERR_NOT_READY;
+  return fail(RT_HIP_ERR_DEVICE, "hipEventQuery", e);
+}
+
+int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
+{
+  if (job == nullptr || rgb == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  size_t const pixels = (size_t)job->params.width * job->params.height;
+  std::vector<float> planes(3 * pixels);
+  // A copy on its own stream: it runs beside the trace kernel and never waits for it.
+  RT_CHECK(hipMemcpyAsync(planes.data(), job->d_planes, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost,
+                          g_lib.copy_stream));
+  RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
+  float const inv = 1.0f / static_cast<float>(job->params.samples_in_row * job->params.samples_in_row);
+  for (size_t i = 0; i < pixels; ++i)
+  {
+    rgb[3 * i + 0] = planes[i] * inv;
+    rgb[3 * i + 1] = planes[pixels + i] * inv;
+    rgb[3 * i + 2] = planes[2 * pixels + i] * inv;
+  }
+  return RT_HIP_OK;
+}
+
+int rt_hip_job_cancel(rt_hip_job * job)
+{
+  if (job == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null job");
+  job->cancelled = true;
+  // Push the pixel queue past the end of the frame: lanes finish the pixel they hold and stop.
+  RT_CHECK(hipMemsetAsync(job->d_stats + kStatsWords, 0x7f, sizeof(uint32_t), g_lib.copy_stream));
+  RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
+  return RT_HIP_OK;
+}
+
+int rt_hip_job_finish(rt_hip_job * job, float * rgb, rt_hip_stats * stats)
+{
+  if (job == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null job");
+  int rc = RT_HIP_OK;
+  hipError_t e = hipEventSynchronize(job->stop);
+  if (e != hipSuccess)
+    rc = fail(RT_HIP_ERR_DEVICE, "hipEventSynchronize", e);
+  size_t const pixels = (size_t)job->params.width * job->params.height;
+  if (rc == RT_HIP_OK && rgb != nullptr)
+  {
+    rc = launch_resolve(job->d_planes, job->d_rgb, job->params.width, job->params.height,
+                        job->params.samples_in_row, g_lib.stream);
+    if (rc == RT_HIP_OK)
+    {
+      e = hipMemcpyAsync(rgb, job->d_rgb, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost, g_lib.stream);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(g_lib.stream);
+      if (e != hipSuccess)
+        rc = fail(RT_HIP_ERR_DEVICE, "image download", e);
+    }
+  }
+  if (rc == RT_HIP_OK && stats != nullptr)
+  {
+    unsigned long long h[kStatsWords] = {0};
+    std::memset(stats, 0, sizeof(*stats));
+    e = hipMemcpy(h, job->d_stats, sizeof(h), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+    {
+      read_stats(h, stats);
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, job->start, job->stop) == hipSuccess)
+        stats->kernel_ms = ms;
+    }
+    else
+      rc = fail(RT_HIP_ERR_DEVICE, "stats download", e);
+  }
+  if (rc == RT_HIP_OK && job->cancelled)
+    rc = fail(RT_HIP_ERR_CANCELLED, "the job was cancelled");
+  free_job(job);
+  return rc;
+}
+
+int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                        const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
+                        void * stream)
+{
+  int const rc = validate(scene, camera, params);
+  if (rc != RT_HIP_OK)
+    return rc;
+  if (d_sum_planes == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null output");
+  // Without a caller buffer the counters (and the queue word behind them) live in a per-process scratch.
+  static unsigned long long * s_scratch = nullptr;
+  unsigned long long * st = static_cast<unsigned long long *>(d_stats);
+  if (st == nullptr)
+  {
+    if (s_scratch == nullptr)
+      RT_CHECK(hipMalloc((void **)&s_scratch, 64));
+    st = s_scratch;
+  }
+  return launch_trace(scene, camera, params, d_sum_planes, st, d_stats != nullptr,
+                      static_cast<hipStream_t>(stream), nullptr);
+}
+
+int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t width, uint32_t height,
+                          uint32_t samples_in_row, void * stream)
+{
+  if (!g_lib.ready)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_init has not been called");
+  if (d_sum_planes == nullptr || d_rgb == nullptr || width == 0 || height == 0 || samples_in_row == 0)
+    return fail(RT_HIP_ERR_INVALID, "bad argument");
+  return launch_resolve(d_sum_planes, d_rgb, width, height, samples_in_row, static_cast<hipStream_t>(stream));
+}
+
+int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                             const rt_hip_trace_params * params, uint32_t launches, float * out_avg_ms,
+                             rt_hip_stats * out_stats)
+{
+  int rc = validate(scene, camera, params);
+  if (rc != RT_HIP_OK)
+    return rc;
+  if (launches == 0 || out_avg_ms == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "bad argument");
+  size_t const pixels = (size_t)params->width * params->height;
+  float * d_planes = nullptr;
+  unsigned long long * d_stats = nullptr;
+  hipEvent_t start = nullptr, stop = nullptr;
+  hipError_t e = hipMalloc((void **)&d_planes, 3 * pixels * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
+  if (e == hipSuccess) e = hipEventCreate(&start);
+  if (e == hipSuccess) e = hipEventCreate(&stop);
+  double total_ms = 0.0;
+  for (uint32_t i = 0; e == hipSuccess && rc == RT_HIP_OK && i < launches; ++i)
+  {
+    // The events bracket the kernel only: the counter reset is enqueued before the start event.
+    TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    prepare_frame(*camera, *params, a);
+    a.spheres = scene->d_spheres;
+    a.sphere_mat = scene->d_sphere_mat;
+    a.materials = scene->d_materials;
+    a.lights = scene->d_lights;
+    a.n_spheres = scene->n_spheres;
+    a.n_materials = scene->n_materials;
+    a.n_lights = scene->n_lights;
+    a.planes = d_planes;
+    a.stats = d_stats;
+    a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
+    e = hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), g_lib.stream);
+    if (e != hipSuccess) break;
+    e = hipEventRecord(start, g_lib.stream);
+    if (e != hipSuccess) break;
+    bool const tiled = scene->n_spheres > kTileSpheres;
+    int const blocks = persistent_blocks(scene->n_spheres, (uint32_t)pixels, tiled);
+    size_t const lds = lds_bytes(scene->n_spheres);
+    if (tiled)
+      hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(kBlock), lds, g_lib.stream, a);
+    else
+      hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(kBlock), lds, g_lib.stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) break;
+    e = hipEventRecord(stop, g_lib.stream);
+    if (e != hipSuccess) break;
+    e = hipEventSynchronize(stop);
+    if (e != hipSuccess) break;
+    float ms = 0.0f;
+    e = hipEventElapsedTime(&ms, start, stop);
+    total_ms += ms;
+  }
+  if (e == hipSuccess && rc == RT_HIP_OK)
+  {
+    *out_avg_ms = (float)(total_ms / launches);
+    if (out_stats)
+    {
+      unsigned long long h[kStatsWords] = {0};
+      std::memset(out_stats, 0, sizeof(*out_stats));
+      e = hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost);
+      if (e == hipSuccess)
+      {
+        read_stats(h, out_stats);
+        out_stats->kernel_ms = *out_avg_ms;
+      }
+    }
+  }
+  if (d_planes) (void)hipFree(d_planes);
+  if (d_stats) (void)hipFree(d_stats);
+  if (start) (void)hipEventDestroy(start);
+  if (stop) (void)hipEventDestroy(stop);
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERR_DEVICE, "rt_hip_time_trace_kernel", e);
+  return rc;
+}
+
+}  // extern "C"

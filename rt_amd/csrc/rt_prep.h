@@ -1,0 +1,89 @@
+// rt_prep.h -- host-side preparation of the kernel arguments: the per-frame camera quantities of
+// Frame::ForEachRayImpl (ray_tracing/frame.cpp:31-43), computed once on the host with the same float
+// operations, and the flattened scene records the kernel reads.
+#pragma once
+
+#include "rt_core.h"
+#include "rt_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace rtc
+{
+inline f3 cross3(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+
+// Fills everything of TraceArgs that depends on the camera and the frame parameters.
+inline void prepare_frame(const rt_hip_camera & cam, const rt_hip_trace_params & p, TraceArgs & a)
+{
+  a.cam_pos = mk3(cam.position[0], cam.position[1], cam.position[2]);
+  a.cam_dir = mk3(cam.direction[0], cam.direction[1], cam.direction[2]);
+  a.background = mk3(cam.background[0], cam.background[1], cam.background[2]);
+  a.cam_right = cross3(mk3(0.0f, 1.0f, 0.0f), a.cam_dir);  // frame.cpp:33
+  a.cam_up = cross3(a.cam_dir, a.cam_right);               // frame.cpp:34
+  a.znear = cam.znear;
+  a.zfar = cam.zfar;
+  a.dw = cam.znear / std::tan(0.5f * cam.fov);                                     // frame.cpp:36
+  float const aspect = static_cast<float>(p.height) / static_cast<float>(p.width);  // frame.cpp:37
+  a.dh = a.dw * aspect;                                                             // frame.cpp:38
+  a.cell_x = 2.0f * a.dw / static_cast<float>(p.width);                             // frame.cpp:40
+  a.cell_y = 2.0f * a.dh / static_cast<float>(p.height);                            // frame.cpp:41
+  a.width = p.width;
+  a.height = p.height;
+  a.s_row = p.samples_in_row;
+  a.s_count = p.samples_in_row * p.samples_in_row;
+  a.flags = p.flags;
+  a.seed = p.seed;
+  a.max_depth = (p.max_depth == 0u || p.max_depth > RT_MAX_DEPTH) ? RT_MAX_DEPTH : p.max_depth;
+  a.slice_count = p.slice_count ? p.slice_count : 1u;
+  a.slice_index = p.slice_index % a.slice_count;
+}
+
+// Scene records in the layout the kernel reads.
+struct FlatScene
+{
+  std::vector<f4> spheres;           // (cx, cy, cz, r*r)
+  std::vector<uint32_t> sphere_mat;  // material index per sphere
+  std::vector<f4> materials;         // 2 per material
+  std::vector<f4> lights;            // 2 per light
+};
+
+inline f4 mk4(float x, float y, float z, float w)
+{
+  f4 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  r.w = w;
+  return r;
+}
+
+inline void flatten_scene(const float * centers_radii, const uint32_t * material_index, uint32_t n,
+                          const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
+                          FlatScene & out)
+{
+  out.spheres.resize(n);
+  out.sphere_mat.assign(material_index, material_index + n);
+  for (uint32_t i = 0; i < n; ++i)
+  {
+    const float * s = centers_radii + 4u * i;
+    out.spheres[i] = mk4(s[0], s[1], s[2], s[3] * s[3]);  // m_radius * m_radius, sphere.cpp:68
+  }
+  out.materials.resize(2u * m);
+  for (uint32_t i = 0; i < m; ++i)
+  {
+    float type_bits;
+    uint32_t const t = mats[i].type;
+    std::memcpy(&type_bits, &t, 4);
+    out.materials[2u * i] = mk4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].roughness);
+    out.materials[2u * i + 1u] = mk4(mats[i].refraction, type_bits, 0.0f, 0.0f);
+  }
+  out.lights.resize(2u * l);
+  for (uint32_t i = 0; i < l; ++i)
+  {
+    out.lights[2u * i] = mk4(lights[i].direction[0], lights[i].direction[1], lights[i].direction[2], 0.0f);
+    out.lights[2u * i + 1u] = mk4(lights[i].color[0], lights[i].color[1], lights[i].color[2], 0.0f);
+  }
+}
+}  // namespace rtc

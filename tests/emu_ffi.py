@@ -1,0 +1,41 @@
+"""ctypes binding of tests/emu/libcore_emu.so: the trace kernel's per-lane state machine compiled for the host.
+
+Test-only.  It exists so the CPU suite can check the kernel's control flow against the oracle without a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rt_amd.ffi import Camera, TraceParams
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PATH = os.path.join(_ROOT, "tests", "emu", "libcore_emu.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            subprocess.check_call(["make", "-C", _ROOT, "-s", "tests/emu/libcore_emu.so"])
+        lib = C.CDLL(_PATH)
+        lib.emu_render.restype = C.c_int
+        lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                   C.POINTER(Camera), C.POINTER(TraceParams), C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def render(scene, p):
+    lib = load()
+    rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    stats = np.zeros(5, dtype=np.uint64)
+    rc = lib.emu_render(scene.centers_radii.ctypes.data, scene.material_index.ctypes.data, scene.sphere_count,
+                        C.cast(scene.materials, C.c_void_p), scene.material_count,
+                        C.cast(scene.lights, C.c_void_p), scene.light_count,
+                        C.byref(scene.camera), C.byref(p), rgb.ctypes.data, stats.ctypes.data)
+    assert rc == 0
+    keys = ["samples", "ray_queries", "hit_queries", "shaded_bounces", "sphere_tests"]
+    return rgb, dict(zip(keys, (int(x) for x in stats)))
