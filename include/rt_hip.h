@@ -78,7 +78,7 @@ typedef struct
   uint32_t height;
   uint32_t samples_in_row; /* S: S*S samples per pixel, regular grid (ray_tracing/frame.cpp:56-66) */
   uint32_t flags;          /* RT_HIP_FLAG_* */
-  uint32_t seed;           /* Philox key word: key = (pixel, sample ^ seed), counter = (bounce, block) */
+  uint32_t seed;           /* Philox4x32-10 key word: key = (pixel, sample ^ seed), counter = (bounce, block) */
   uint32_t max_depth;      /* 0 -> 10 (demos/demo_frame_cpu.cpp:10); 1 = primary hit + direct light only */
   uint32_t slice_index;    /* see "Conventions" */
   uint32_t slice_count;    /* 0 or 1 -> the whole sample space */
@@ -89,10 +89,11 @@ typedef struct
 {
   uint64_t samples;        /* camera samples traced */
   uint64_t ray_queries;    /* nearest-hit + shadow queries the algorithm asks for, each against all spheres */
-  uint64_t hit_queries;    /* nearest-hit queries that found a hit */
+  uint64_t hit_queries;    /* queries that found a hit */
   uint64_t shaded_bounces; /* hits that ran direct light + specular */
-  uint64_t sphere_tests;   /* ray-sphere tests executed (includes padding lanes and unused scatter rays) */
-  float kernel_ms;         /* device time of the trace kernel(s), HIP events on the launch stream; 0 if not measured */
+  uint64_t sphere_tests;   /* ray-sphere filter tests executed (every traced ray against every sphere) */
+  uint64_t exact_tests;    /* candidates the filter let through, intersected exactly */
+  float kernel_ms;         /* device time of the trace kernel, HIP events on the launch stream; 0 if not measured */
   uint32_t reserved;
 } rt_hip_stats;
 

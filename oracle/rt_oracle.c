@@ -104,15 +104,44 @@ void orc_ball(float radius, float u1, float u2, float u3, float out[3])
   out[2] = z * rad;
 }
 
-static void draw_block(const orc_params * params, uint32_t pixel, uint32_t sample, uint32_t bounce,
-                       uint32_t block, float u[4])
+static void philox_block(const orc_params * params, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                         uint32_t block, uint32_t w[4])
 {
   uint32_t const ctr[4] = {bounce, block, 0u, 0u};
   uint32_t const key[2] = {pixel, sample ^ params->seed};
-  uint32_t w[4];
   orc_philox4x32_10(ctr, key, w);
+}
+
+/* Block 0 of a bounce: three 24-bit uniforms for the scatter ball and one for the glass branch. */
+static void draw_scatter(const orc_params * params, uint32_t pixel, uint32_t sample, uint32_t bounce, float u[4])
+{
+  uint32_t w[4];
+  philox_block(params, pixel, sample, bounce, 0u, w);
   for (int i = 0; i < 4; ++i)
     u[i] = orc_uniform(w[i]);
+}
+
+/* Blocks 1 + 2*light and 2 + 2*light of a bounce: their eight words are cut into sixteen 16-bit halves
+ * h[0..15] (low half first); shadow sample j takes h[3j], h[3j+1], h[3j+2] as uniforms h / 65536. */
+static void draw_shadow_jitter(const orc_params * params, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                               uint32_t light, v3 jitter[ORC_LIGHT_SAMPLES])
+{
+  uint32_t w[8];
+  philox_block(params, pixel, sample, bounce, 1u + 2u * light, w);
+  philox_block(params, pixel, sample, bounce, 2u + 2u * light, w + 4);
+  for (uint32_t j = 0; j < ORC_LIGHT_SAMPLES; ++j)
+  {
+    float u[3], b[3];
+    for (uint32_t q = 0; q < 3; ++q)
+    {
+      uint32_t const h = 3u * j + q;
+      uint32_t const word = w[h >> 1];
+      uint32_t const half = (h & 1u) ? (word >> 16) : (word & 0xFFFFu);
+      u[q] = (float)half * (1.0f / 65536.0f);
+    }
+    orc_ball(0.25f, u[0], u[1], u[2], b);
+    jitter[j] = ld(b);
+  }
 }
 
 /* ---- camera: Frame::ForEachRayImpl, frame.cpp:31-62 ---- */
@@ -438,7 +467,7 @@ static v3 ray_trace(const orc_scene * scene, const orc_camera * cam, const orc_p
     if (!deterministic)
     {
       float b[3];
-      draw_block(params, pixel, sample, count, 0u, u);
+      draw_scatter(params, pixel, sample, count, u);
       orc_ball(1.0f, u[0], u[1], u[2], b);
       ball = ld(b);
     }
@@ -458,16 +487,9 @@ static v3 ray_trace(const orc_scene * scene, const orc_camera * cam, const orc_p
     {
       v3 jitter[ORC_LIGHT_SAMPLES];
       for (uint32_t j = 0; j < ORC_LIGHT_SAMPLES; ++j)
-      {
         jitter[j] = mk(0.0f, 0.0f, 0.0f);
-        if (!deterministic)
-        {
-          float ju[4], b[3];
-          draw_block(params, pixel, sample, count, 1u + li * ORC_LIGHT_SAMPLES + j, ju);
-          orc_ball(0.25f, ju[0], ju[1], ju[2], b);
-          jitter[j] = ld(b);
-        }
-      }
+      if (!deterministic)
+        draw_shadow_jitter(params, pixel, sample, count, li, jitter);
       diffuse = add(diffuse, trace_light(scene, scene->lights + li, mat, h.pos, h.normal, jitter, stats));
       specular = add(specular, get_specular(scene->lights + li, mat, dir, h.normal));
     }

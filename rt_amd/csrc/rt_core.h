@@ -1,20 +1,33 @@
 // rt_core.h -- per-lane path state machine of the gfx950 trace kernel.
 //
-// One lane carries one camera sample at a time.  Every trip round the main loop a lane runs one
-// "ray pass": RT_RAYS (6) rays that share an origin are tested against every sphere of the scene.
-// A pass is either
-//   * a shade pass: the 5 jittered shadow rays of DirectionalLight::TraceLight
-//     (ray_tracing/directional_light.cpp:15-35) plus the scattered ray whose nearest hit starts the
-//     next bounce (demos/demo_frame_cpu.cpp:33,50) -- all six leave the same hit point; or
-//   * a primary pass: the next 6 sub-samples of the lane's pixel (ray_tracing/frame.cpp:56-66) -- all
-//     six leave the camera.
-// Sharing the origin lets (origin - centre) and c = |origin - centre|^2 - r^2 be computed once per
-// sphere for six rays.  A lane whose path ends starts its next sample at once, and a lane whose
-// pixel is finished pulls a new pixel from the frame-wide queue, so the wave keeps all 64 lanes on
-// live rays whatever the bounce depth of its neighbours.
+// One lane carries one camera sample at a time and never waits for its neighbours' paths: a lane whose
+// path ends starts its next sample on the next trip round the loop, and a lane whose pixel is finished
+// pulls a new pixel from the frame-wide queue.  A trip has two stages.
 //
-// The file is plain C++ over a handful of macros so the same state machine also compiles for the
-// host, one lane at a time, which is how the logic is debugged without a GPU (tests/emu).
+//   Stage P  lanes without a hit to shade trace primary rays (ray_tracing/frame.cpp:56-66) until they
+//            have one; the stage repeats while enough lanes are still looking.
+//   Stage S  lanes with a hit run Material::Scatter and the specular term, then one "ray pass": the 5
+//            jittered shadow rays of DirectionalLight::TraceLight (ray_tracing/directional_light.cpp:15-35)
+//            and the scattered ray whose nearest hit starts the next bounce (demos/demo_frame_cpu.cpp:33,50).
+//            All six leave the same point.
+//
+// Ray against all spheres, in two steps:
+//   filter   a ray from O along unit D can only hit sphere (C, r) in front of O if
+//            dot(O - C, D) <= -sqrt(|O - C|^2 - r^2).  The right-hand side depends on the origin only, so
+//            it is computed once per sphere for the six rays of a pass (and once per frame for the
+//            camera); each ray-sphere test is then 3 FMAs, a compare and an add-with-carry that shifts
+//            the result into a per-lane candidate mask.  A small margin keeps the filter conservative.
+//   resolve  the few candidates are intersected exactly as Sphere::TraceNearest does
+//            (ray_tracing/sphere.cpp:63-81), operation for operation, with IEEE sqrt and division and
+//            without FMA contraction, keeping the nearest one as TraceNearestInHitableCollection does
+//            (ray_tracing/hitable_object.hpp:71-87).  Shadow rays stop at their first accepted hit.
+// Everything downstream of a hit (hit point, normal, scatter, specular, accumulation) uses the same
+// un-contracted IEEE operations as the CPU path, so the only approximate arithmetic is in the filter,
+// in the shadow-ray directions and in the random ball sampler.
+//
+// This translation unit is compiled with -ffp-contract=off; the filter asks for FMAs explicitly.
+// The file is plain C++ over a handful of macros so the same state machine also compiles for the host,
+// one lane at a time, which is how the logic is debugged without a GPU (tests/emu).
 #pragma once
 
 #include <stdint.h>
@@ -32,11 +45,15 @@
 
 namespace rtc
 {
-constexpr int RT_RAYS = 6;           // rays per pass (5 shadow + 1 scatter, or 6 primaries)
-constexpr int RT_LIGHT_SAMPLES = 5;  // ray_tracing/directional_light.cpp:13
+constexpr int RT_RAYS = 6;             // rays per shade pass: 5 shadow + 1 scattered
+constexpr int RT_LIGHT_SAMPLES = 5;    // ray_tracing/directional_light.cpp:13
 constexpr uint32_t RT_MAX_DEPTH = 10;  // demos/demo_frame_cpu.cpp:10
-constexpr float RT_EPS = 1e-5f;      // ray_tracing/types.hpp:9
+constexpr float RT_EPS = 1e-5f;        // ray_tracing/types.hpp:9
 constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
+constexpr uint32_t RT_PAD = 4;         // sphere arrays are padded to a multiple of this with never-hit entries
+constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
+constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
 
 constexpr uint32_t RT_MATTE = 0, RT_METAL = 1, RT_GLASS = 2;  // ray_tracing/types.hpp:15-17
 constexpr uint32_t RT_FLAG_DETERMINISTIC = 1u;
@@ -48,6 +65,10 @@ struct f3
 struct f4
 {
   float x, y, z, w;
+};
+struct u4
+{
+  uint32_t x, y, z, w;
 };
 
 RT_HD f3 mk3(float x, float y, float z)
@@ -63,50 +84,61 @@ RT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 RT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 RT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// ---- hardware math: one instruction each on gfx950 (about 1 ulp); libm on the host ----
+// ---- approximate hardware math (one instruction each on gfx950, about 1 ulp); libm on the host ----
 #if defined(__HIPCC__)
 RT_FN float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-RT_FN float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 RT_FN float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 RT_FN float hw_sin_rev(float r) { return __builtin_amdgcn_sinf(r); }  // sin(2*pi*r)
 RT_FN float hw_cos_rev(float r) { return __builtin_amdgcn_cosf(r); }
 RT_FN float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 RT_FN float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
-RT_FN float hw_min(float a, float b) { return fminf(a, b); }
-RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
-RT_FN float hw_abs(float a) { return fabsf(a); }
+RT_FN float hw_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+RT_FN int hw_clz(uint32_t x) { return __clz((int)x); }
+RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
+RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
+// mask = 2 * mask + (x >= bound): a compare into VCC and an add-with-carry that shifts it in.
+RT_FN void push_ge(uint32_t & mask, float x, float bound)
+{
+  asm("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(x), "v"(bound) : "vcc");
+}
 #else
 RT_FN float hw_sqrt(float x) { return sqrtf(x); }
-RT_FN float hw_rcp(float x) { return 1.0f / x; }
 RT_FN float hw_rsq(float x) { return 1.0f / sqrtf(x); }
 RT_FN float hw_sin_rev(float r) { return sinf(6.28318530717958647692f * r); }
 RT_FN float hw_cos_rev(float r) { return cosf(6.28318530717958647692f * r); }
 RT_FN float hw_exp2(float x) { return exp2f(x); }
 RT_FN float hw_log2(float x) { return log2f(x); }
-RT_FN float hw_min(float a, float b) { return fminf(a, b); }
-RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
-RT_FN float hw_abs(float a) { return fabsf(a); }
+RT_FN float hw_fma(float a, float b, float c) { return a * b + c; }
 RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+RT_FN int hw_clz(uint32_t x) { return __builtin_clz(x); }
+RT_FN uint32_t f2u(float f)
+{
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
+RT_FN void push_ge(uint32_t & mask, float x, float bound) { mask = mask + mask + (x >= bound ? 1u : 0u); }
 #endif
 
-RT_FN f3 normalize3(f3 v) { return v * hw_rsq(dot3(v, v)); }
+// ---- exact helpers: the GLSL definitions glm follows, IEEE sqrt and division ----
+RT_FN float minf(float a, float b) { return (b < a) ? b : a; }  // std::min
+RT_FN float maxf(float a, float b) { return (a < b) ? b : a; }  // std::max
+RT_FN float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }
+RT_FN f3 normalize3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+RT_FN f3 normalize3_fast(f3 v) { return v * hw_rsq(dot3(v, v)); }
+RT_FN f3 mix3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
 RT_FN float pow5(float x)
 {
   float const x2 = x * x;
   return x2 * x2 * x;
 }
-RT_FN float clampf(float x, float lo, float hi) { return hw_min(hw_max(x, lo), hi); }
-RT_FN f3 mix3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
 
 // ---- Philox4x32-10, key = (pixel, sample ^ seed), counter = (bounce, block, 0, 0) ----
-struct u4
-{
-  uint32_t x, y, z, w;
-};
-
 RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -131,14 +163,15 @@ RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
   return o;
 }
 
-RT_FN float uniform01(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
+RT_FN float uniform24(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
+RT_FN float uniform16(uint32_t half) { return (float)half * (1.0f / 65536.0f); }
 
 // Uniform point in a ball of radius R from three uniforms: direction uniform on the sphere, radius
 // R * u^(1/3).  Same law as glm::ballRand with a fixed draw count, so no lane waits on a rejection loop.
 RT_FN f3 ball3(float radius, float u1, float u2, float u3)
 {
   float const z = 1.0f - 2.0f * u1;
-  float const s = hw_sqrt(hw_max(0.0f, 1.0f - z * z));
+  float const s = hw_sqrt(maxf(0.0f, 1.0f - z * z));
   float const rad = radius * hw_exp2(hw_log2(u3) * (1.0f / 3.0f));
   return mk3((s * hw_cos_rev(u2)) * rad, (s * hw_sin_rev(u2)) * rad, z * rad);
 }
@@ -147,11 +180,13 @@ RT_FN f3 ball3(float radius, float u1, float u2, float u3)
 struct TraceArgs
 {
   // scene, device memory
-  const f4 * spheres;          // n_spheres x (cx, cy, cz, r*r)
+  const f4 * spheres;          // n_padded x (cx, cy, cz, r*r): what the exact intersection reads
+  const f4 * filter;           // n_padded x (cx, cy, cz, r*r widened by the filter margin)
+  const f4 * camtab;           // n_padded x (centre - camera, filter bound): the primary-ray filter
   const uint32_t * sphere_mat; // n_spheres
   const f4 * materials;        // n_materials x 2: (albedo rgb, roughness), (refraction, type bits, 0, 0)
   const f4 * lights;           // n_lights x 2: (direction xyz, 0), (colour rgb, 0)
-  uint32_t n_spheres, n_materials, n_lights;
+  uint32_t n_spheres, n_padded, n_materials, n_lights;
   // camera, precomputed on the host exactly as Frame::ForEachRayImpl does (ray_tracing/frame.cpp:33-41)
   f3 cam_pos, cam_dir, cam_right, cam_up, background;
   float znear, zfar, dw, dh, cell_x, cell_y;
@@ -159,52 +194,69 @@ struct TraceArgs
   uint32_t width, height, s_row, s_count;  // s_count = s_row * s_row
   uint32_t flags, seed, max_depth, slice_index, slice_count;
   // outputs
-  float * planes;            // 3 planes of width*height un-normalised sums
-  uint32_t * queue_counter;  // next pixel to hand out
-  unsigned long long * stats; // 5 counters: samples, ray queries, hit queries, shaded bounces, sphere tests
+  float * planes;             // 3 planes of width*height un-normalised sums
+  uint32_t * queue_counter;   // next pixel to hand out
+  unsigned long long * stats; // counters, see rt_hip.hip
 };
 
 struct LaneCounters
 {
-  uint32_t samples, queries, hits, shaded, passes;
+  uint32_t samples, queries, hits, shaded, filter_tests, exact_tests;
 };
 
-// Per-lane state.  Arrays are only ever indexed by compile-time constants (unrolled loops), so they
-// stay in registers.
+// The filter.  With d = C - O and unit D, the ray can hit the sphere in front of O only if
+// dot(d, D) >= sqrt(c), c = |d|^2 - r^2.  The bound is taken from c - m (|d|^2 + r^2), m = RT_FILTER_MARGIN
+// (the stored r2f is r^2 (1 + m)), so that rounding here (FMAs, approximate sqrt: a few ulps of |d|^2) can
+// never reject a ray the exact intersection would accept; an origin on or inside the widened sphere gives
+// bound 0.
+RT_FN float filter_bound(float dx, float dy, float dz, float r2f)
+{
+  float const dd = hw_fma(dz, dz, hw_fma(dy, dy, dx * dx));
+  return hw_sqrt(hw_max(hw_fma(dd, (float)(1.0 - RT_FILTER_MARGIN), -r2f), 0.0f));
+}
+
+// Sphere::TraceNearest, ray_tracing/sphere.cpp:63-81, operation for operation (a = dot(D, D) hoisted).
+// The reference takes min((-b - s) / 2a, (-b + s) / 2a); a > 0 and s >= 0, and IEEE division by a positive
+// number is monotone, so the minimum is always the first quotient, bit for bit.
+RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out)
+{
+  f3 const d = o - mk3(s.x, s.y, s.z);
+  float const b = 2.0f * dot3(d, dir);
+  float const c = dot3(d, d) - s.w;
+  float const disc = b * b - 4 * a * c;
+  if (disc < 0.0f)
+    return false;
+  float const sq = sqrtf(disc);
+  float const t = (-b - sq) / (2.0f * a);
+  if (t < tmin || t > tmax)
+    return false;
+  t_out = t;
+  return true;
+}
+
+// Per-lane state.
 struct Lane
 {
   // pixel being accumulated
   uint32_t pixel;
-  uint32_t s_gen;  // next owned sample index not yet put into a primary batch (>= s_count: none left)
-  float dxp, dyp;  // dx, dy of the pixel's top-left corner (ray_tracing/frame.cpp:49,52)
+  uint32_t s_next;  // next owned sample index of the pixel (>= s_count: none left)
+  float dxp, dyp;   // dx, dy of the pixel's top-left corner (ray_tracing/frame.cpp:49,52)
   f3 sum;
   bool alive, need_pixel;
-  // primary batch: nearest hits of up to 6 consecutive owned samples, consumed front first
-  float bt[RT_RAYS];
-  int bi[RT_RAYS];
-  uint32_t b_cnt;
-  uint32_t b_s;  // sample index of the front entry
   // current path
   uint32_t sample;  // sample index (RNG key)
   uint32_t depth;   // entries pushed so far ("scatterResultsCount")
   bool has_hit;     // a hit waits to be shaded
+  bool shading;     // a shade pass sequence (one pass per light) is in flight
   f3 hp, hn, hd;    // hit point, normal, incoming direction
   int hidx;         // sphere hit
-  // shading in flight (between ray set-up and the end of the last light's pass)
-  int mode;  // 0 = none, 1 = primary pass, 2 = shade pass
-  uint32_t li;  // light of the current shade pass
-  f3 spec, diffuse;
-  float e;
-  float w[RT_LIGHT_SAMPLES];  // max(0, dot(shadow dir, n))
-  f3 m_albedo;
-  float m_refraction;
-  f3 sdir;  // scattered direction
-  float s_a;  // dot(sdir, sdir)
-  float nx_ta;
-  int nx_i;  // nearest hit of the scattered ray (from the first light's pass)
+  // shading in flight
+  uint32_t li;      // light of the current shade pass
+  f3 spec, diffuse, m_albedo, sdir;
+  float e, m_refraction, s_a;
+  float nx_t;
+  int nx_i;  // nearest hit of the scattered ray (found during the first light's pass)
 };
-
-constexpr int MODE_NONE = 0, MODE_PRIMARY = 1, MODE_SHADE = 2;
 
 // Frame::ForEachRayImpl, ray_tracing/frame.cpp:58-62: direction of sub-sample `sample` = sx * S + sy.
 RT_FN f3 primary_dir(const TraceArgs & A, float dxp, float dyp, uint32_t sample)
@@ -213,8 +265,7 @@ RT_FN f3 primary_dir(const TraceArgs & A, float dxp, float dyp, uint32_t sample)
   uint32_t const sy = sample - sx * A.s_row;
   float const sdx = dxp + A.cell_x * (float)sx / (float)A.s_row;
   float const sdy = dyp - A.cell_y * (float)sy / (float)A.s_row;
-  f3 const v = (A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * sdx;
-  return normalize3(v);
+  return normalize3((A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * sdx);
 }
 
 RT_FN void begin_pixel(const TraceArgs & A, Lane & L, uint32_t pixel)
@@ -226,17 +277,15 @@ RT_FN void begin_pixel(const TraceArgs & A, Lane & L, uint32_t pixel)
   L.dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;
   L.sum = mk3(0.0f, 0.0f, 0.0f);
   uint32_t const g = A.slice_count;
-  // first sample s with (s + pixel) % g == slice_index
-  L.s_gen = (A.slice_index + g - pixel % g) % g;
-  L.b_cnt = 0;
+  L.s_next = (A.slice_index + g - pixel % g) % g;  // first sample s with (s + pixel) % g == slice_index
 }
 
 // Material::Scatter for the three materials, ray_tracing/default_materials.cpp:11-67.
 RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n, f3 ball, float xi,
                    f3 & out_dir, float & out_e)
 {
-  float const dn = dot3(rd, n);
-  f3 const refl = rd - n * dn * 2.0f;  // glm::reflect
+  float const dn = dot3(n, rd);
+  f3 const refl = rd - n * dn * 2.0f;  // glm::reflect(I, N) = I - N * dot(N, I) * 2
   if (type == RT_MATTE)
   {
     out_dir = normalize3(n + ball);
@@ -250,7 +299,7 @@ RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n
   }
   else
   {
-    float vdn = dn;
+    float vdn = dot3(rd, n);
     f3 outward;
     float eta;
     if (vdn > 0.0f)
@@ -270,7 +319,7 @@ RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n
     float const k = 1.0f - eta * eta * (1.0f - d * d);
     f3 refr = mk3(0.0f, 0.0f, 0.0f);
     if (k >= 0.0f)
-      refr = rd * eta - outward * (eta * d + hw_sqrt(k));
+      refr = rd * eta - outward * (eta * d + sqrtf(k));
     float ref = 1.0f;
     if (dot3(refr, refr) > RT_EPS)
     {
@@ -286,17 +335,16 @@ RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n
 // DirectionalLight::GetSpecular, ray_tracing/directional_light.cpp:37-60.
 RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, float m_roughness, float m_refraction, f3 rd, f3 n)
 {
-  float const vdn = clampf(-dot3(rd, n), 0.0f, 1.0f);
-  float const ndl = clampf(-dot3(n, ldir), 0.0f, 1.0f);
+  float const vdn = clampf(dot3(-rd, n), 0.0f, 1.0f);
+  float const ndl = clampf(dot3(n, -ldir), 0.0f, 1.0f);
   f3 const h = -normalize3(ldir + rd);
   float const ndh = clampf(dot3(n, h), RT_EPS, 1.0f);
-  float const vdh = clampf(-dot3(rd, h), 0.0f, 1.0f);
-  float const g = (hw_abs(vdh) >= RT_EPS) ? hw_min(1.0f, 2.0f * ndh * hw_min(vdn, ndl) / vdh) : 1.0f;
+  float const vdh = clampf(dot3(-rd, h), 0.0f, 1.0f);
+  float const g = (fabsf(vdh) >= RT_EPS) ? minf(1.0f, 2.0f * ndh * minf(vdn, ndl) / vdh) : 1.0f;
   float const ndh2 = ndh * ndh;
-  float const roughness = hw_max(m_roughness, 0.03f);
+  float const roughness = maxf(m_roughness, 0.03f);
   float const r2 = roughness * roughness;
-  float const dm = hw_exp2(((ndh2 - 1.0f) / (r2 * ndh2)) * 1.44269504088896340736f) /
-                   (4.0f * r2 * ndh2 * ndh2);
+  float const dm = expf((ndh2 - 1.0f) / (r2 * ndh2)) / (4.0f * r2 * ndh2 * ndh2);
   float const f0 = (1.0f - m_refraction) / (1.0f + m_refraction);
   float const f2 = f0 * f0;
   float const f = f2 + (1.0f - f2) * pow5(1.0f - vdn);
@@ -316,7 +364,7 @@ RT_FN f3 accumulate(const f4 * stack, uint32_t stride, uint32_t count)
     att = att * (mk3(s.x, s.y, s.z) * rest);
     rest *= s.w;
     i--;
-    if (hw_abs(rest) < RT_EPS)
+    if (fabsf(rest) < RT_EPS)
       break;
   }
   return att * 0.5f;
@@ -332,40 +380,181 @@ RT_FN void push(f4 * stack, uint32_t stride, uint32_t depth, f3 l, float e)
   stack[depth * stride] = s;
 }
 
-// The ray pass over one resident tile of spheres: Sphere::TraceNearest (ray_tracing/sphere.cpp:63-81)
-// for RT_RAYS rays with a common origin, keeping the nearest accepted root per ray as
-// TraceNearestInHitableCollection does (ray_tracing/hitable_object.hpp:71-87; strictly smaller t
-// replaces, so the first sphere wins ties).  Works on ta = t * a (a = dot(D, D)), so the range test is
-// ta >= tlo * a and ta < best where best starts at thi * a.  A negative discriminant gives a NaN root
-// which fails both comparisons.  `base` is the scene index of sph[0].
-RT_FN void ray_pass(const f4 * sph, uint32_t count, uint32_t base, f3 o, const f3 (&dir)[RT_RAYS],
-                    const float (&a)[RT_RAYS], const float (&tlo_a)[RT_RAYS], float (&best)[RT_RAYS],
-                    int (&idx)[RT_RAYS])
+// Filter of one ray against `count` (<= RT_CHUNK, a multiple of RT_PAD) camera-table entries
+// (centre - camera, bound): entry j of the chunk ends up in bit (count - 1 - j) of the mask.
+RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
 {
-#pragma unroll 2
-  for (uint32_t i = 0; i < count; ++i)
+  uint32_t mask = 0;
+  for (uint32_t j = 0; j < count; j += RT_PAD)
   {
-    f4 const s = sph[i];
-    float const dx = o.x - s.x, dy = o.y - s.y, dz = o.z - s.z;
-    float const c = (dx * dx + dy * dy + dz * dz) - s.w;
-    int const id = (int)(base + i);
 #pragma unroll
-    for (int r = 0; r < RT_RAYS; ++r)
+    for (uint32_t u = 0; u < RT_PAD; ++u)
     {
-      float const hb = dx * dir[r].x + dy * dir[r].y + dz * dir[r].z;
-      float const disc = hb * hb - a[r] * c;
-      float const ta = -hb - hw_sqrt(disc);
-      bool const take = (ta >= tlo_a[r]) && (ta < best[r]);
-      best[r] = take ? ta : best[r];
-      idx[r] = take ? id : idx[r];
+      f4 const e = tab[j + u];
+      float const x = hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, e.x * dir.x));
+      push_ge(mask, x, e.w);
+    }
+  }
+  return mask;
+}
+
+// Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK, a multiple of RT_PAD) spheres.
+RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask)[RT_RAYS])
+{
+#pragma unroll
+  for (int r = 0; r < RT_RAYS; ++r)
+    mask[r] = 0;
+  for (uint32_t j = 0; j < count; j += 2)
+  {
+#pragma unroll
+    for (uint32_t u = 0; u < 2; ++u)
+    {
+      f4 const s = sph[j + u];
+      float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
+      float const bound = filter_bound(dx, dy, dz, s.w);
+#pragma unroll
+      for (int r = 0; r < RT_RAYS; ++r)
+      {
+        float const x = hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, dx * dir[r].x));
+        push_ge(mask[r], x, bound);
+      }
     }
   }
 }
 
-// What the enclosing kernel provides.  any(): true if the predicate holds for any lane that shares this
-// lane's loop trip (the wave, or the block when sphere tiles are re-staged inside the loop);
-// fetch_pixel(): hands a fresh pixel index to each lane that asks (RT_INVALID when the frame is used up);
-// run_pass(): executes ray_pass over every sphere of the scene.
+// Takes the candidate with the lowest sphere index out of a chunk mask; returns its index in the chunk.
+RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
+{
+  uint32_t const bit = 31u - (uint32_t)hw_clz(mask);
+  mask &= ~(1u << bit);
+  return count - 1u - bit;
+}
+
+// What the enclosing kernel provides (Env):
+//   any(p)            true if p holds for any lane sharing this lane's loop trips (the wave; the block when
+//                     sphere tiles are re-staged inside the loop)
+//   count(p)          number of such lanes for which p holds
+//   any_wave(p)       true if p holds for any lane of the wave
+//   fetch_pixel(need) hands a fresh pixel index to each lane that asks (RT_INVALID when the frame is used up)
+//   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i)
+//   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
+//                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
+//                     tile_data(primary)
+template <class Env>
+RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, float a, float & best_t,
+                         int & best_i, LaneCounters & cnt)
+{
+  best_i = -1;
+  best_t = 0.0f;
+  for (uint32_t k = 0; k < env.tiles(); ++k)
+  {
+    uint32_t const tile_count = env.load_tile(k, true);
+    uint32_t const tile_base = env.tile_base(k);
+    const f4 * tab = env.tile_data(true);
+    for (uint32_t c0 = 0; c0 < tile_count; c0 += RT_CHUNK)
+    {
+      uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
+      uint32_t mask = filter_chunk_1(tab + c0, count, dir);
+      if (!active)
+        mask = 0;
+      while (env.any_wave(mask != 0u))
+      {
+        if (mask != 0u)
+        {
+          int const i = (int)(tile_base + c0 + pop_candidate(mask, count));
+          float t;
+          cnt.exact_tests += 1;
+          if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t) && (best_i < 0 || t < best_t))
+          {
+            best_i = i;
+            best_t = t;
+          }
+        }
+      }
+    }
+  }
+  if (active)
+    cnt.filter_tests += A.n_spheres;
+}
+
+template <class Env>
+RT_FN void trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
+                      const bool (&on)[RT_RAYS], bool (&occluded)[RT_LIGHT_SAMPLES], float & near_t,
+                      int & near_i, LaneCounters & cnt)
+{
+  bool live[RT_RAYS];
+#pragma unroll
+  for (int r = 0; r < RT_RAYS; ++r)
+    live[r] = on[r];
+#pragma unroll
+  for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
+    occluded[r] = false;
+  near_i = -1;
+  near_t = 0.0f;
+  for (uint32_t k = 0; k < env.tiles(); ++k)
+  {
+    uint32_t const tile_count = env.load_tile(k, false);
+    uint32_t const tile_base = env.tile_base(k);
+    const f4 * sph = env.tile_data(false);
+    for (uint32_t c0 = 0; c0 < tile_count; c0 += RT_CHUNK)
+    {
+      uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
+      uint32_t mask[RT_RAYS];
+      filter_chunk_6(sph + c0, count, o, dir, mask);
+      uint32_t any_mask = 0;
+#pragma unroll
+      for (int r = 0; r < RT_RAYS; ++r)
+      {
+        mask[r] = live[r] ? mask[r] : 0u;
+        any_mask |= mask[r];
+      }
+      if (!env.any_wave(any_mask != 0u))
+        continue;
+      // Shadow rays: existence of a hit in [0.001, 1000] is all TraceLight uses.
+#pragma unroll
+      for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
+      {
+        while (env.any_wave(mask[r] != 0u))
+        {
+          if (mask[r] != 0u)
+          {
+            int const i = (int)(tile_base + c0 + pop_candidate(mask[r], count));
+            float t;
+            cnt.exact_tests += 1;
+            if (exact_hit(o, dir[r], a[r], env.sphere(i), 0.001f, 1000.0f, t))
+            {
+              occluded[r] = true;
+              live[r] = false;
+              mask[r] = 0u;
+            }
+          }
+        }
+      }
+      // Scattered ray: nearest hit; secondary hits start at 0.001 (demos/demo_frame_cpu.cpp:53).
+      while (env.any_wave(mask[RT_RAYS - 1] != 0u))
+      {
+        if (mask[RT_RAYS - 1] != 0u)
+        {
+          int const i = (int)(tile_base + c0 + pop_candidate(mask[RT_RAYS - 1], count));
+          float t;
+          cnt.exact_tests += 1;
+          if (exact_hit(o, dir[RT_RAYS - 1], a[RT_RAYS - 1], env.sphere(i), 0.001f, A.zfar, t) &&
+              (near_i < 0 || t < near_t))
+          {
+            near_i = i;
+            near_t = t;
+          }
+        }
+      }
+    }
+  }
+  uint32_t rays_on = 0;
+#pragma unroll
+  for (int r = 0; r < RT_RAYS; ++r)
+    rays_on += on[r] ? 1u : 0u;
+  cnt.filter_tests += rays_on * A.n_spheres;
+}
+
 template <class Env>
 RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t stride, LaneCounters & cnt)
 {
@@ -373,45 +562,70 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
   L.alive = true;
   L.need_pixel = true;
   L.has_hit = false;
-  L.mode = MODE_NONE;
-  L.b_cnt = 0;
-  L.b_s = 0;
-  L.s_gen = 0;
+  L.shading = false;
   L.pixel = 0;
+  L.s_next = 0;
   L.depth = 0;
   L.sample = 0;
   L.li = 0;
-  L.sum = mk3(0.0f, 0.0f, 0.0f);
+  L.hidx = 0;
+  L.nx_i = -1;
+  L.nx_t = 0.0f;
+  L.e = 0.0f;
+  L.m_refraction = 0.0f;
+  L.s_a = 1.0f;
+  L.sum = L.hp = L.hn = L.hd = L.spec = L.diffuse = L.m_albedo = L.sdir = mk3(0.0f, 0.0f, 0.0f);
   L.dxp = L.dyp = 0.0f;
-#pragma unroll
-  for (int r = 0; r < RT_RAYS; ++r)
-  {
-    L.bt[r] = 0.0f;
-    L.bi[r] = -1;
-  }
   bool const deterministic = (A.flags & RT_FLAG_DETERMINISTIC) != 0u;
-  uint32_t const stride_g = A.slice_count;
+  uint32_t const np = A.width * A.height;
 
   for (;;)
   {
-    // ---- 1. cheap transitions: consume primary results, finish pixels, fetch new pixels ----
-    for (int it = 0; it < 4; ++it)
+    // ================= stage P: primary rays for lanes with nothing to shade =================
+    for (;;)
     {
-      while (L.alive && !L.need_pixel && !L.has_hit && L.mode == MODE_NONE)
+      bool need = L.alive && !L.has_hit && !L.shading;
+      // Pixel complete: one plain store per plane, each pixel written by exactly one lane.
+      if (need && !L.need_pixel && L.s_next >= A.s_count)
       {
-        if (L.b_cnt > 0)
+        A.planes[L.pixel] = L.sum.x;
+        A.planes[np + L.pixel] = L.sum.y;
+        A.planes[2u * np + L.pixel] = L.sum.z;
+        L.need_pixel = true;
+      }
+      bool const ask = need && L.need_pixel;
+      if (env.any(ask))
+      {
+        uint32_t const p = env.fetch_pixel(ask);
+        if (ask)
         {
-          float const ta = L.bt[0];
-          int const hi = L.bi[0];
-          uint32_t const s = L.b_s;
-#pragma unroll
-          for (int r = 0; r + 1 < RT_RAYS; ++r)
+          if (p == RT_INVALID)
+            L.alive = false;
+          else
           {
-            L.bt[r] = L.bt[r + 1];
-            L.bi[r] = L.bi[r + 1];
+            begin_pixel(A, L, p);
+            L.need_pixel = false;
           }
-          L.b_cnt -= 1;
-          L.b_s += stride_g;
+        }
+      }
+      need = need && L.alive;
+      // A pixel without owned samples (more slices than samples) is stored as zeros on the next round.
+      bool const active = need && L.s_next < A.s_count;
+      if (env.any(active))
+      {
+        uint32_t const s = L.s_next;
+        f3 d = mk3(0.0f, 0.0f, 1.0f);
+        if (active)
+        {
+          d = primary_dir(A, L.dxp, L.dyp, s);
+          L.s_next += A.slice_count;
+        }
+        float const a = dot3(d, d);
+        float t;
+        int hi;
+        trace_primary(A, env, active, d, a, t, hi, cnt);
+        if (active)
+        {
           cnt.samples += 1;
           cnt.queries += 1;
           if (hi < 0)
@@ -422,10 +636,8 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           else
           {
             cnt.hits += 1;
-            f3 const d = primary_dir(A, L.dxp, L.dyp, s);
-            float const t = ta / dot3(d, d);
             f4 const sp = env.sphere(hi);
-            L.hp = A.cam_pos + d * t;
+            L.hp = A.cam_pos + d * t;  // Ray::PointAt
             L.hn = normalize3(L.hp - mk3(sp.x, sp.y, sp.z));
             L.hd = d;
             L.hidx = hi;
@@ -434,68 +646,41 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             L.sample = s;
           }
         }
-        else if (L.s_gen < A.s_count)
-        {
-          L.mode = MODE_PRIMARY;
-        }
-        else
-        {
-          // Pixel complete: one plain store per plane, each pixel written by exactly one lane.
-          uint32_t const np = A.width * A.height;
-          A.planes[L.pixel] = L.sum.x;
-          A.planes[np + L.pixel] = L.sum.y;
-          A.planes[2u * np + L.pixel] = L.sum.z;
-          L.need_pixel = true;
-        }
       }
-      bool const need = L.alive && L.need_pixel;
-      if (!env.any(need))
+      bool const still = L.alive && !L.has_hit && !L.shading;
+      int const n_still = env.count(still);
+      if (n_still == 0)
         break;
-      uint32_t const p = env.fetch_pixel(need);
-      if (need)
-      {
-        if (p == RT_INVALID)
-        {
-          L.alive = false;
-        }
-        else
-        {
-          begin_pixel(A, L, p);
-          L.need_pixel = false;
-        }
-      }
+      bool const someone_ready = env.any(L.alive && (L.has_hit || L.shading));
+      if (someone_ready && n_still <= RT_P_THRESHOLD)
+        break;
     }
     if (!env.any(L.alive))
       break;
 
-    // ---- 2. ray set-up ----
-    f3 origin = mk3(0.0f, 0.0f, 0.0f);
+    // ================= stage S: shade the hits =================
     f3 dir[RT_RAYS];
-    float a[RT_RAYS], tlo_a[RT_RAYS], best[RT_RAYS];
-    int idx[RT_RAYS];
+    float a[RT_RAYS];
+    bool on[RT_RAYS];
+    float w[RT_LIGHT_SAMPLES];
 #pragma unroll
     for (int r = 0; r < RT_RAYS; ++r)
     {
-      // A disabled ray: zero direction and a negative upper bound, so no root is ever accepted.
-      dir[r] = mk3(0.0f, 0.0f, 0.0f);
-      a[r] = 0.0f;
-      tlo_a[r] = 0.0f;
-      best[r] = -1.0f;
-      idx[r] = -1;
+      dir[r] = mk3(0.0f, 0.0f, 1.0f);
+      a[r] = 1.0f;
+      on[r] = false;
     }
+#pragma unroll
+    for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+      w[j] = 0.0f;
 
-    if (L.alive && L.has_hit && L.mode == MODE_NONE)
+    if (L.alive && L.has_hit)
     {
       // A new hit: Material::Scatter first (demos/demo_frame_cpu.cpp:38).
       uint32_t const mi = env.sphere_material(L.hidx);
       f4 const m0 = A.materials[2u * mi];
       f4 const m1 = A.materials[2u * mi + 1u];
-      uint32_t mtype;
-#if defined(__HIPCC__)
-      mtype = __float_as_uint(m1.y);
-#else
-      memcpy(&mtype, &m1.y, 4);
-#endif
+      uint32_t const mtype = f2u(m1.y);
       L.m_albedo = mk3(m0.x, m0.y, m0.z);
       float const m_rough = m0.w;
       L.m_refraction = m1.x;
@@ -504,13 +689,13 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       float xi = 0.5f;
       if (!deterministic)
       {
-        u4 const w = philox4x32_10(L.depth, 0u, 0u, 0u, L.pixel, L.sample ^ A.seed);
-        ball = ball3(1.0f, uniform01(w.x), uniform01(w.y), uniform01(w.z));
-        xi = uniform01(w.w);
+        u4 const rw = philox4x32_10(L.depth, 0u, 0u, 0u, L.pixel, L.sample ^ A.seed);
+        ball = ball3(1.0f, uniform24(rw.x), uniform24(rw.y), uniform24(rw.z));
+        xi = uniform24(rw.w);
       }
       scatter(mtype, m_rough, L.m_refraction, L.hd, L.hn, ball, xi, L.sdir, L.e);
       L.has_hit = false;
-      if (hw_abs(L.e) < RT_EPS)
+      if (fabsf(L.e) < RT_EPS)
       {
         // Absorbed: the entry becomes the environment colour and the path ends
         // (demos/demo_frame_cpu.cpp:39-45).
@@ -532,83 +717,66 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         L.li = 0;
         L.s_a = dot3(L.sdir, L.sdir);
         L.nx_i = -1;
-        L.nx_ta = 0.0f;
-        L.mode = MODE_SHADE;
+        L.nx_t = 0.0f;
+        L.shading = true;
       }
     }
 
-    if (L.alive && L.mode == MODE_SHADE)
+    bool const in_pass = L.alive && L.shading;
+    if (in_pass)
     {
-      origin = L.hp;
       if (L.li < A.n_lights)
       {
         f4 const l0 = A.lights[2u * L.li];
         f3 const to_light = mk3(-l0.x, -l0.y, -l0.z);
+        f3 jit[RT_LIGHT_SAMPLES];
+#pragma unroll
+        for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+          jit[j] = mk3(0.0f, 0.0f, 0.0f);
+        if (!deterministic)
+        {
+          // 15 uniforms of 16 bits from two Philox blocks: half-words h[0..15], ball j takes h[3j..3j+2].
+          u4 const p0 = philox4x32_10(L.depth, 1u + 2u * L.li, 0u, 0u, L.pixel, L.sample ^ A.seed);
+          u4 const p1 = philox4x32_10(L.depth, 2u + 2u * L.li, 0u, 0u, L.pixel, L.sample ^ A.seed);
+          uint32_t const wd[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+          {
+            float u[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+            {
+              int const h = 3 * j + q;
+              uint32_t const word = wd[h >> 1];
+              u[q] = uniform16((h & 1) ? (word >> 16) : (word & 0xFFFFu));
+            }
+            jit[j] = ball3(0.25f, u[0], u[1], u[2]);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
         {
-          f3 jit = mk3(0.0f, 0.0f, 0.0f);
-          if (!deterministic)
-          {
-            u4 const w = philox4x32_10(L.depth, 1u + L.li * RT_LIGHT_SAMPLES + (uint32_t)j, 0u, 0u, L.pixel,
-                                       L.sample ^ A.seed);
-            jit = ball3(0.25f, uniform01(w.x), uniform01(w.y), uniform01(w.z));
-          }
-          f3 const rd = normalize3(to_light + jit);
+          f3 const rd = normalize3_fast(to_light + jit[j]);
           dir[j] = rd;
           a[j] = dot3(rd, rd);
-          tlo_a[j] = 0.001f * a[j];
-          best[j] = 1000.0f * a[j];
-          L.w[j] = hw_max(0.0f, dot3(rd, L.hn));
+          on[j] = true;
+          w[j] = maxf(0.0f, dot3(rd, L.hn));
         }
       }
       if (L.li == 0)
       {
         dir[RT_RAYS - 1] = L.sdir;
         a[RT_RAYS - 1] = L.s_a;
-        tlo_a[RT_RAYS - 1] = 0.001f * L.s_a;  // secondary hits start at 0.001 (demos/demo_frame_cpu.cpp:53)
-        best[RT_RAYS - 1] = A.zfar * L.s_a;
+        on[RT_RAYS - 1] = true;
       }
-      cnt.passes += 1;
-    }
-    else if (L.alive && L.mode == MODE_PRIMARY)
-    {
-      origin = A.cam_pos;
-      L.b_s = L.s_gen;
-      uint32_t n = 0;
-#pragma unroll
-      for (int r = 0; r < RT_RAYS; ++r)
-      {
-        if (L.s_gen < A.s_count)
-        {
-          f3 const d = primary_dir(A, L.dxp, L.dyp, L.s_gen);
-          dir[r] = d;
-          a[r] = dot3(d, d);
-          tlo_a[r] = A.znear * a[r];
-          best[r] = A.zfar * a[r];
-          L.s_gen += stride_g;
-          n += 1;
-        }
-      }
-      L.b_cnt = n;
-      cnt.passes += 1;
     }
 
-    // ---- 3. the pass: every ray against every sphere ----
-    env.run_pass(origin, dir, a, tlo_a, best, idx);
+    bool occluded[RT_LIGHT_SAMPLES];
+    float near_t;
+    int near_i;
+    trace_pass(A, env, L.hp, dir, a, on, occluded, near_t, near_i, cnt);
 
-    // ---- 4. take the results ----
-    if (L.alive && L.mode == MODE_PRIMARY)
-    {
-#pragma unroll
-      for (int r = 0; r < RT_RAYS; ++r)
-      {
-        L.bt[r] = best[r];
-        L.bi[r] = idx[r];
-      }
-      L.mode = MODE_NONE;
-    }
-    else if (L.alive && L.mode == MODE_SHADE)
+    if (in_pass)
     {
       if (L.li < A.n_lights)
       {
@@ -621,17 +789,16 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
         {
-          bool const occluded = idx[j] >= 0;
-          color = color + (occluded ? tint : lcol) * L.w[j];
-          cnt.hits += occluded ? 1u : 0u;
+          color = color + (occluded[j] ? tint : lcol) * w[j];
+          cnt.hits += occluded[j] ? 1u : 0u;
         }
-        L.diffuse = L.diffuse + color * (1.0f / (float)RT_LIGHT_SAMPLES);
+        L.diffuse = L.diffuse + color / (float)RT_LIGHT_SAMPLES;
         cnt.queries += RT_LIGHT_SAMPLES;
       }
       if (L.li == 0)
       {
-        L.nx_i = idx[RT_RAYS - 1];
-        L.nx_ta = best[RT_RAYS - 1];
+        L.nx_i = near_i;
+        L.nx_t = near_t;
       }
       L.li += 1;
       if (L.li >= A.n_lights)
@@ -641,7 +808,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         push(stack, stride, L.depth, (L.m_albedo + L.diffuse) + L.spec, L.e);
         L.depth += 1;
         cnt.shaded += 1;
-        L.mode = MODE_NONE;
+        L.shading = false;
         bool ended = true;
         if (L.depth < A.max_depth)
         {
@@ -650,9 +817,8 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           if (L.nx_i >= 0)
           {
             cnt.hits += 1;
-            float const t = L.nx_ta / L.s_a;
             f4 const sp = env.sphere(L.nx_i);
-            f3 const p = L.hp + L.sdir * t;
+            f3 const p = L.hp + L.sdir * L.nx_t;
             L.hn = normalize3(p - mk3(sp.x, sp.y, sp.z));
             L.hp = p;
             L.hd = L.sdir;

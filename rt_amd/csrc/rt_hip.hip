@@ -1,7 +1,7 @@
 // rt_hip.hip -- gfx950 kernels and the C ABI of the MI355X ray-tracing backend (include/rt_hip.h).
 //
 // Kernels
-//   trace_kernel<false>  persistent waves; the whole scene (<= kTileSpheres spheres) sits in LDS for the
+//   trace_kernel<false>  persistent waves; the whole scene (<= kResidentSpheres spheres) sits in LDS for the
 //                        life of the block; every lane runs the path state machine of rt_core.h and pulls
 //                        pixels from one frame-wide atomic counter, 64 lanes per atomic (ballot + prefix
 //                        count).  Waves never wait for each other.
@@ -10,7 +10,10 @@
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
 //                        16 bytes per lane per access; the only HBM-bound pass.
 //
-// LDS per block: 10 x float4 path stack per lane (40 KB at 256 lanes) + the sphere tile (16 B per sphere).
+//   camtab_kernel        per-frame table of the primary-ray filter, one entry per sphere.
+//
+// LDS per block: 10 x float4 path stack per lane (40 KB at 256 lanes) + the resident scene and its camera
+// table (48 B per sphere), or one 16 KB staging tile for scenes above kResidentSpheres spheres.
 #include "rt_core.h"
 #include "rt_hip.h"
 #include "rt_prep.h"
@@ -30,85 +33,83 @@ namespace
 using namespace rtc;
 
 constexpr int kBlock = 256;               // 4 waves
-constexpr uint32_t kTileSpheres = 2048;   // 32 KB of LDS per tile
-constexpr uint32_t kStatsWords = 5;
+constexpr int kWavesPerSimd = 3;          // blocks per CU the register budget is sized for
+constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS whole (48 B per sphere)
+constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
+constexpr uint32_t kStatsWords = 6;
 
 // ---------------------------------------------------------------- device side
 
+// One atomic per wave hands consecutive pixels to the lanes that asked.
+__device__ __forceinline__ uint32_t wave_fetch_pixel(uint32_t * counter, uint32_t total_pixels, bool need)
+{
+  unsigned long long const mask = __ballot(need);
+  uint32_t const lane = __lane_id();
+  int const leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (need && (int)lane == leader)
+    base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader < 0 ? 0 : leader);
+  uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t const p = base + rank;
+  return (need && p < total_pixels) ? p : RT_INVALID;
+}
+
+// The whole scene is resident in LDS; waves never wait for each other.
 struct WaveEnv
 {
   const TraceArgs & A;
-  const f4 * sph;  // LDS: the whole scene
+  const f4 * filt;   // LDS: n_padded filter records
+  const f4 * cam;    // LDS: n_padded camera-table records
+  const f4 * exact;  // LDS: n_padded exact records
   uint32_t total_pixels;
 
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
-
-  // One atomic per wave hands consecutive pixels to the lanes that asked.
+  __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
+  __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ uint32_t fetch_pixel(bool need) const
   {
-    unsigned long long const mask = __ballot(need);
-    uint32_t const lane = __lane_id();
-    int const leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (need && (int)lane == leader)
-      base = atomicAdd(A.queue_counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader < 0 ? 0 : leader);
-    uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t const p = base + rank;
-    return (need && p < total_pixels) ? p : RT_INVALID;
+    return wave_fetch_pixel(A.queue_counter, total_pixels, need);
   }
-
-  __device__ __forceinline__ f4 sphere(int i) const { return sph[i]; }
+  __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-
-  __device__ __forceinline__ void run_pass(f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
-                                           const float (&tlo_a)[RT_RAYS], float (&best)[RT_RAYS],
-                                           int (&idx)[RT_RAYS]) const
-  {
-    ray_pass(sph, A.n_spheres, 0u, o, dir, a, tlo_a, best, idx);
-  }
+  __device__ __forceinline__ uint32_t tiles() const { return 1u; }
+  __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
+  __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return A.n_padded; }
+  __device__ __forceinline__ const f4 * tile_data(bool primary) const { return primary ? cam : filt; }
 };
 
+// Larger scenes: the block re-stages the spheres (or the camera table) through one LDS tile inside every
+// pass, so all of its waves take the same trips and every loop decision is block-wide.
 struct BlockEnv
 {
   const TraceArgs & A;
   f4 * tile;  // LDS: kTileSpheres entries
   uint32_t total_pixels;
 
-  // The block's waves share the staging barriers inside run_pass, so every loop decision is block-wide.
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
-
+  __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
+  __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ uint32_t fetch_pixel(bool need) const
   {
-    unsigned long long const mask = __ballot(need);
-    uint32_t const lane = __lane_id();
-    int const leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (need && (int)lane == leader)
-      base = atomicAdd(A.queue_counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader < 0 ? 0 : leader);
-    uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t const p = base + rank;
-    return (need && p < total_pixels) ? p : RT_INVALID;
+    return wave_fetch_pixel(A.queue_counter, total_pixels, need);
   }
-
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-
-  __device__ __forceinline__ void run_pass(f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
-                                           const float (&tlo_a)[RT_RAYS], float (&best)[RT_RAYS],
-                                           int (&idx)[RT_RAYS]) const
+  __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + kTileSpheres - 1u) / kTileSpheres; }
+  __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * kTileSpheres; }
+  __device__ __forceinline__ uint32_t load_tile(uint32_t k, bool primary) const
   {
-    for (uint32_t base = 0; base < A.n_spheres; base += kTileSpheres)
-    {
-      uint32_t const count = min(kTileSpheres, A.n_spheres - base);
-      __syncthreads();  // everyone is done with the previous tile
-      for (uint32_t i = threadIdx.x; i < count; i += kBlock)
-        tile[i] = A.spheres[base + i];
-      __syncthreads();
-      ray_pass(tile, count, base, o, dir, a, tlo_a, best, idx);
-    }
+    uint32_t const base = k * kTileSpheres;
+    uint32_t const count = min(kTileSpheres, A.n_padded - base);
+    const f4 * src = (primary ? A.camtab : A.filter) + base;
+    __syncthreads();  // everyone is done with the previous tile
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock)
+      tile[i] = src[i];
+    __syncthreads();
+    return count;
   }
+  __device__ __forceinline__ const f4 * tile_data(bool) const { return tile; }
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -120,14 +121,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 template <bool kTiled>
-__global__ __launch_bounds__(kBlock, 2) void trace_kernel(TraceArgs A)
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  f4 * stack = reinterpret_cast<f4 *>(lds_raw);                  // [RT_MAX_DEPTH][kBlock]
-  f4 * sph = stack + RT_MAX_DEPTH * kBlock;                      // sphere tile
+  f4 * stack = reinterpret_cast<f4 *>(lds_raw);  // [RT_MAX_DEPTH][kBlock]
+  f4 * sph = stack + RT_MAX_DEPTH * kBlock;      // resident scene, or the staging tile
   uint32_t const total_pixels = A.width * A.height;
 
-  LaneCounters cnt = {0u, 0u, 0u, 0u, 0u};
+  LaneCounters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
   if constexpr (kTiled)
   {
     BlockEnv env{A, sph, total_pixels};
@@ -135,27 +136,52 @@ __global__ __launch_bounds__(kBlock, 2) void trace_kernel(TraceArgs A)
   }
   else
   {
-    for (uint32_t i = threadIdx.x; i < A.n_spheres; i += kBlock)
-      sph[i] = A.spheres[i];
+    f4 * cam = sph + A.n_padded;
+    f4 * exact = cam + A.n_padded;
+    for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
+    {
+      sph[i] = A.filter[i];
+      cam[i] = A.camtab[i];
+      exact[i] = A.spheres[i];
+    }
     __syncthreads();
-    WaveEnv env{A, sph, total_pixels};
+    WaveEnv env{A, sph, cam, exact, total_pixels};
     trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
 
   // Work counters: one 64-bit atomic per wave and counter.
-  uint32_t const samples = wave_sum(cnt.samples);
-  uint32_t const queries = wave_sum(cnt.queries);
-  uint32_t const hits = wave_sum(cnt.hits);
-  uint32_t const shaded = wave_sum(cnt.shaded);
-  uint32_t const passes = wave_sum(cnt.passes);
+  uint32_t const c0 = wave_sum(cnt.samples);
+  uint32_t const c1 = wave_sum(cnt.queries);
+  uint32_t const c2 = wave_sum(cnt.hits);
+  uint32_t const c3 = wave_sum(cnt.shaded);
+  uint32_t const c4 = wave_sum(cnt.filter_tests);
+  uint32_t const c5 = wave_sum(cnt.exact_tests);
   if (A.stats != nullptr && __lane_id() == 0)
   {
-    atomicAdd(&A.stats[0], (unsigned long long)samples);
-    atomicAdd(&A.stats[1], (unsigned long long)queries);
-    atomicAdd(&A.stats[2], (unsigned long long)hits);
-    atomicAdd(&A.stats[3], (unsigned long long)shaded);
-    atomicAdd(&A.stats[4], (unsigned long long)passes * (unsigned long long)(RT_RAYS * A.n_spheres));
+    atomicAdd(&A.stats[0], (unsigned long long)c0);
+    atomicAdd(&A.stats[1], (unsigned long long)c1);
+    atomicAdd(&A.stats[2], (unsigned long long)c2);
+    atomicAdd(&A.stats[3], (unsigned long long)c3);
+    atomicAdd(&A.stats[4], (unsigned long long)c4);
+    atomicAdd(&A.stats[5], (unsigned long long)c5);
   }
+}
+
+// The primary-ray filter table: per (padded) sphere, (centre - camera, filter bound).  One thread per entry.
+__global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ filter, f4 * __restrict__ camtab,
+                                                     uint32_t n_padded, f3 cam_pos)
+{
+  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_padded)
+    return;
+  f4 const s = filter[i];
+  float const dx = s.x - cam_pos.x, dy = s.y - cam_pos.y, dz = s.z - cam_pos.z;
+  f4 e;
+  e.x = dx;
+  e.y = dy;
+  e.z = dz;
+  e.w = filter_bound(dx, dy, dz, s.w);
+  camtab[i] = e;
 }
 
 // planes: 3 x n floats; rgb: n x 3 floats.  Each lane takes 4 pixels: three 16-byte loads, three 16-byte
@@ -225,16 +251,17 @@ Library g_lib;
 
 struct rt_hip_scene
 {
-  f4 * d_spheres = nullptr;
+  f4 * d_spheres = nullptr;  // exact records, n_padded
+  f4 * d_filter = nullptr;   // filter records, n_padded
+  f4 * d_camtab = nullptr;   // n_padded, rewritten by every trace for its camera
   uint32_t * d_sphere_mat = nullptr;
   f4 * d_materials = nullptr;
   f4 * d_lights = nullptr;
-  uint32_t n_spheres = 0, n_materials = 0, n_lights = 0;
+  uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
 };
 
 struct rt_hip_job
 {
-  TraceArgs args;
   rt_hip_trace_params params;
   float * d_planes = nullptr;
   float * d_rgb = nullptr;
@@ -245,22 +272,25 @@ struct rt_hip_job
 
 namespace
 {
-size_t lds_bytes(uint32_t n_spheres)
+bool is_tiled(uint32_t n_padded) { return n_padded > kResidentSpheres; }
+
+// Path stacks + either the resident scene (filter, camera table and exact records) or one staging tile.
+size_t lds_bytes(uint32_t n_padded)
 {
-  uint32_t const tile = std::min(n_spheres, kTileSpheres);
-  return sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock + std::max(tile, 1u));
+  uint32_t const entries = is_tiled(n_padded) ? kTileSpheres : std::max(3u * n_padded, 1u);
+  return sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock + entries);
 }
 
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
 // more lanes than pixels.
-int persistent_blocks(uint32_t n_spheres, uint32_t pixels, bool tiled)
+int persistent_blocks(uint32_t n_padded, uint32_t pixels)
 {
   int per_cu = 0;
   hipError_t e;
-  if (tiled)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true>, kBlock, lds_bytes(n_spheres));
+  if (is_tiled(n_padded))
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true>, kBlock, lds_bytes(n_padded));
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false>, kBlock, lds_bytes(n_spheres));
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false>, kBlock, lds_bytes(n_padded));
   if (e != hipSuccess || per_cu < 1)
     per_cu = 1;
   long long blocks = (long long)per_cu * std::max(g_lib.compute_units, 1);
@@ -286,38 +316,52 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
   return RT_HIP_OK;
 }
 
-// Enqueues counter reset + trace kernel on `stream`.  d_stats points at kStatsWords counters followed by
-// the queue counter (one 8-byte slot).
+// Enqueues, on `stream`: counter reset, the camera table for this frame's camera, the trace kernel.
+// d_stats points at kStatsWords counters followed by the queue counter (one 8-byte slot).  When events are
+// given they are recorded directly around the trace kernel.  The camera table lives in the scene, so one
+// scene carries one trace at a time.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
                  float * d_planes, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
-                 TraceArgs * out_args)
+                 hipEvent_t ev_start, hipEvent_t ev_stop)
 {
   TraceArgs a;
   std::memset(&a, 0, sizeof(a));
   prepare_frame(*camera, *p, a);
   a.spheres = scene->d_spheres;
+  a.filter = scene->d_filter;
+  a.camtab = scene->d_camtab;
   a.sphere_mat = scene->d_sphere_mat;
   a.materials = scene->d_materials;
   a.lights = scene->d_lights;
   a.n_spheres = scene->n_spheres;
+  a.n_padded = scene->n_padded;
   a.n_materials = scene->n_materials;
   a.n_lights = scene->n_lights;
   a.planes = d_planes;
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
-  if (out_args)
-    *out_args = a;
 
   RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
-  bool const tiled = scene->n_spheres > kTileSpheres;
+  if (scene->n_padded > 0)
+  {
+    int const tab_blocks = (int)((scene->n_padded + 255u) / 256u);
+    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, scene->d_camtab,
+                       scene->n_padded, a.cam_pos);
+    RT_CHECK(hipGetLastError());
+  }
+  bool const tiled = is_tiled(scene->n_padded);
   uint32_t const pixels = p->width * p->height;
-  int const blocks = persistent_blocks(scene->n_spheres, pixels, tiled);
-  size_t const lds = lds_bytes(scene->n_spheres);
+  int const blocks = persistent_blocks(scene->n_padded, pixels);
+  size_t const lds = lds_bytes(scene->n_padded);
+  if (ev_start)
+    RT_CHECK(hipEventRecord(ev_start, stream));
   if (tiled)
     hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, a);
   else
     hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, a);
   RT_CHECK(hipGetLastError());
+  if (ev_stop)
+    RT_CHECK(hipEventRecord(ev_stop, stream));
   return RT_HIP_OK;
 }
 
@@ -340,6 +384,7 @@ void read_stats(const unsigned long long * h, rt_hip_stats * out)
   out->hit_queries = h[2];
   out->shaded_bounces = h[3];
   out->sphere_tests = h[4];
+  out->exact_tests = h[5];
 }
 
 void free_job(rt_hip_job * job)
@@ -450,6 +495,7 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   if (s == nullptr)
     return fail(RT_HIP_ERR_DEVICE, "out of host memory");
   s->n_spheres = sphere_count;
+  s->n_padded = static_cast<uint32_t>(fs.spheres.size());
   s->n_materials = material_count;
   s->n_lights = light_count;
   auto upload = [](void ** dst, const void * src, size_t bytes) -> hipError_t {
@@ -460,6 +506,10 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
     return e;
   };
   hipError_t e = upload((void **)&s->d_spheres, fs.spheres.data(), fs.spheres.size() * sizeof(f4));
+  if (e == hipSuccess)
+    e = upload((void **)&s->d_filter, fs.filter.data(), fs.filter.size() * sizeof(f4));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&s->d_camtab, std::max<size_t>(fs.spheres.size() * sizeof(f4), 16));
   if (e == hipSuccess)
     e = upload((void **)&s->d_sphere_mat, fs.sphere_mat.data(), fs.sphere_mat.size() * sizeof(uint32_t));
   if (e == hipSuccess)
@@ -480,6 +530,8 @@ void rt_hip_scene_destroy(rt_hip_scene * scene)
   if (scene == nullptr)
     return;
   if (scene->d_spheres) (void)hipFree(scene->d_spheres);
+  if (scene->d_filter) (void)hipFree(scene->d_filter);
+  if (scene->d_camtab) (void)hipFree(scene->d_camtab);
   if (scene->d_sphere_mat) (void)hipFree(scene->d_sphere_mat);
   if (scene->d_materials) (void)hipFree(scene->d_materials);
   if (scene->d_lights) (void)hipFree(scene->d_lights);
@@ -508,19 +560,13 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
   if (e == hipSuccess) e = hipEventCreate(&job->stop);
   // Unfinished pixels read as black in snapshots.
   if (e == hipSuccess) e = hipMemsetAsync(job->d_planes, 0, 3 * pixels * sizeof(float), g_lib.stream);
-  if (e == hipSuccess) e = hipEventRecord(job->start, g_lib.stream);
   if (e != hipSuccess)
   {
     free_job(job);
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   }
-  rc = launch_trace(scene, camera, params, job->d_planes, job->d_stats, true, g_lib.stream, &job->args);
-  if (rc == RT_HIP_OK)
-  {
-    e = hipEventRecord(job->stop, g_lib.stream);
-    if (e != hipSuccess)
-      rc = fail(RT_HIP_ERR_DEVICE, "hipEventRecord", e);
-  }
+  rc = launch_trace(scene, camera, params, job->d_planes, job->d_stats, true, g_lib.stream, job->start,
+                    job->stop);
   if (rc != RT_HIP_OK)
   {
     (void)hipStreamSynchronize(g_lib.stream);
@@ -636,7 +682,7 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
     st = s_scratch;
   }
   return launch_trace(scene, camera, params, d_sum_planes, st, d_stats != nullptr,
-                      static_cast<hipStream_t>(stream), nullptr);
+                      static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t width, uint32_t height,
@@ -669,37 +715,12 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
   double total_ms = 0.0;
   for (uint32_t i = 0; e == hipSuccess && rc == RT_HIP_OK && i < launches; ++i)
   {
-    // The events bracket the kernel only: the counter reset is enqueued before the start event.
-    TraceArgs a;
-    std::memset(&a, 0, sizeof(a));
-    prepare_frame(*camera, *params, a);
-    a.spheres = scene->d_spheres;
-    a.sphere_mat = scene->d_sphere_mat;
-    a.materials = scene->d_materials;
-    a.lights = scene->d_lights;
-    a.n_spheres = scene->n_spheres;
-    a.n_materials = scene->n_materials;
-    a.n_lights = scene->n_lights;
-    a.planes = d_planes;
-    a.stats = d_stats;
-    a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
-    e = hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), g_lib.stream);
-    if (e != hipSuccess) break;
-    e = hipEventRecord(start, g_lib.stream);
-    if (e != hipSuccess) break;
-    bool const tiled = scene->n_spheres > kTileSpheres;
-    int const blocks = persistent_blocks(scene->n_spheres, (uint32_t)pixels, tiled);
-    size_t const lds = lds_bytes(scene->n_spheres);
-    if (tiled)
-      hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(kBlock), lds, g_lib.stream, a);
-    else
-      hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(kBlock), lds, g_lib.stream, a);
-    e = hipGetLastError();
-    if (e != hipSuccess) break;
-    e = hipEventRecord(stop, g_lib.stream);
-    if (e != hipSuccess) break;
+    rc = launch_trace(scene, camera, params, d_planes, d_stats, true, g_lib.stream, start, stop);
+    if (rc != RT_HIP_OK)
+      break;
     e = hipEventSynchronize(stop);
-    if (e != hipSuccess) break;
+    if (e != hipSuccess)
+      break;
     float ms = 0.0f;
     e = hipEventElapsedTime(&ms, start, stop);
     total_ms += ms;

@@ -43,13 +43,14 @@ inline void prepare_frame(const rt_hip_camera & cam, const rt_hip_trace_params &
 // Scene records in the layout the kernel reads.
 struct FlatScene
 {
-  std::vector<f4> spheres;           // (cx, cy, cz, r*r)
+  std::vector<f4> spheres;           // (cx, cy, cz, r*r), padded to a multiple of RT_PAD
+  std::vector<f4> filter;            // (cx, cy, cz, r*r widened by the filter margin), padded likewise
   std::vector<uint32_t> sphere_mat;  // material index per sphere
   std::vector<f4> materials;         // 2 per material
   std::vector<f4> lights;            // 2 per light
 };
 
-inline f4 mk4(float x, float y, float z, float w)
+RT_HD f4 mk4(float x, float y, float z, float w)
 {
   f4 r;
   r.x = x;
@@ -63,12 +64,18 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
                           const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                           FlatScene & out)
 {
-  out.spheres.resize(n);
+  uint32_t const padded = (n + RT_PAD - 1u) / RT_PAD * RT_PAD;
+  // Padding entries can never pass the filter: a hugely negative r^2 puts every origin far outside.
+  out.spheres.assign(padded, mk4(0.0f, 0.0f, 0.0f, -1e30f));
+  out.filter.assign(padded, mk4(0.0f, 0.0f, 0.0f, -1e30f));
   out.sphere_mat.assign(material_index, material_index + n);
   for (uint32_t i = 0; i < n; ++i)
   {
     const float * s = centers_radii + 4u * i;
-    out.spheres[i] = mk4(s[0], s[1], s[2], s[3] * s[3]);  // m_radius * m_radius, sphere.cpp:68
+    float const r2 = s[3] * s[3];  // m_radius * m_radius, sphere.cpp:68
+    out.spheres[i] = mk4(s[0], s[1], s[2], r2);
+    double const widened = static_cast<double>(r2) * (1.0 + RT_FILTER_MARGIN);
+    out.filter[i] = mk4(s[0], s[1], s[2], std::nextafter(static_cast<float>(widened), INFINITY));
   }
   out.materials.resize(2u * m);
   for (uint32_t i = 0; i < m; ++i)

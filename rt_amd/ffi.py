@@ -53,6 +53,7 @@ class Stats(C.Structure):
         ("hit_queries", C.c_uint64),
         ("shaded_bounces", C.c_uint64),
         ("sphere_tests", C.c_uint64),
+        ("exact_tests", C.c_uint64),
         ("kernel_ms", C.c_float),
         ("reserved", C.c_uint32),
     ]

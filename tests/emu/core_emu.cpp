@@ -12,9 +12,14 @@ struct HostEnv
 {
   const rtc::TraceArgs & A;
   uint32_t total;
+  uint32_t tile_size;
   uint32_t next = 0;
+  uint32_t cur_count = 0;
+  const rtc::f4 * cur = nullptr;
 
   bool any(bool p) { return p; }
+  int count(bool p) { return p ? 1 : 0; }
+  bool any_wave(bool p) { return p; }
   uint32_t fetch_pixel(bool need)
   {
     if (!need)
@@ -24,24 +29,41 @@ struct HostEnv
   }
   rtc::f4 sphere(int i) const { return A.spheres[i]; }
   uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-  void run_pass(rtc::f3 o, const rtc::f3 (&dir)[rtc::RT_RAYS], const float (&a)[rtc::RT_RAYS],
-                const float (&tlo_a)[rtc::RT_RAYS], float (&best)[rtc::RT_RAYS], int (&idx)[rtc::RT_RAYS])
+  uint32_t tiles() const { return (A.n_padded + tile_size - 1) / tile_size; }
+  uint32_t tile_base(uint32_t k) const { return k * tile_size; }
+  uint32_t load_tile(uint32_t k, bool primary)
   {
-    rtc::ray_pass(A.spheres, A.n_spheres, 0u, o, dir, a, tlo_a, best, idx);
+    uint32_t const base = k * tile_size;
+    cur = (primary ? A.camtab : A.filter) + base;
+    cur_count = (A.n_padded - base < tile_size) ? (A.n_padded - base) : tile_size;
+    return cur_count;
   }
+  const rtc::f4 * tile_data(bool) const { return cur; }
 };
 }  // namespace
 
+// tile_size: records per staged tile, a multiple of 4 (exercises the multi-tile path when smaller than the scene).
 extern "C" int emu_render(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                           const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
-                          const rt_hip_camera * cam, const rt_hip_trace_params * p, float * rgb,
-                          unsigned long long * stats5)
+                          const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
+                          float * rgb, unsigned long long * stats6)
 {
   rtc::FlatScene fs;
   rtc::flatten_scene(centers_radii, material_index, n, mats, m, lights, l, fs);
   rtc::TraceArgs a{};
   rtc::prepare_frame(*cam, *p, a);
+  uint32_t const padded = static_cast<uint32_t>(fs.filter.size());
+  std::vector<rtc::f4> camtab(padded);
+  for (uint32_t i = 0; i < padded; ++i)
+  {
+    float const dx = fs.filter[i].x - a.cam_pos.x, dy = fs.filter[i].y - a.cam_pos.y,
+                dz = fs.filter[i].z - a.cam_pos.z;
+    camtab[i] = rtc::mk4(dx, dy, dz, rtc::filter_bound(dx, dy, dz, fs.filter[i].w));
+  }
   a.spheres = fs.spheres.data();
+  a.filter = fs.filter.data();
+  a.camtab = camtab.data();
+  a.n_padded = padded;
   a.sphere_mat = fs.sphere_mat.data();
   a.materials = fs.materials.data();
   a.lights = fs.lights.data();
@@ -56,20 +78,21 @@ extern "C" int emu_render(const float * centers_radii, const uint32_t * material
 
   std::vector<rtc::f4> stack(rtc::RT_MAX_DEPTH);
   rtc::LaneCounters cnt{};
-  HostEnv env{a, np};
+  HostEnv env{a, np, tile_size ? tile_size : (padded ? padded : 4u)};
   rtc::trace_loop(a, env, stack.data(), 1u, cnt);
 
   float const inv = 1.0f / static_cast<float>(p->samples_in_row * p->samples_in_row);
   for (uint32_t i = 0; i < np; ++i)
     for (uint32_t c = 0; c < 3; ++c)
       rgb[3u * (size_t)i + c] = planes[(size_t)c * np + i] * inv;
-  if (stats5)
+  if (stats6)
   {
-    stats5[0] = cnt.samples;
-    stats5[1] = cnt.queries;
-    stats5[2] = cnt.hits;
-    stats5[3] = cnt.shaded;
-    stats5[4] = (unsigned long long)cnt.passes * rtc::RT_RAYS * n;
+    stats6[0] = cnt.samples;
+    stats6[1] = cnt.queries;
+    stats6[2] = cnt.hits;
+    stats6[3] = cnt.shaded;
+    stats6[4] = cnt.filter_tests;
+    stats6[5] = cnt.exact_tests;
   }
   return 0;
 }

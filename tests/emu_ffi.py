@@ -23,19 +23,19 @@ def load():
         lib = C.CDLL(_PATH)
         lib.emu_render.restype = C.c_int
         lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
-                                   C.POINTER(Camera), C.POINTER(TraceParams), C.c_void_p, C.c_void_p]
+                                   C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
 
-def render(scene, p):
+def render(scene, p, tile_size=0):
     lib = load()
     rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
-    stats = np.zeros(5, dtype=np.uint64)
+    stats = np.zeros(6, dtype=np.uint64)
     rc = lib.emu_render(scene.centers_radii.ctypes.data, scene.material_index.ctypes.data, scene.sphere_count,
                         C.cast(scene.materials, C.c_void_p), scene.material_count,
                         C.cast(scene.lights, C.c_void_p), scene.light_count,
-                        C.byref(scene.camera), C.byref(p), rgb.ctypes.data, stats.ctypes.data)
+                        C.byref(scene.camera), C.byref(p), tile_size, rgb.ctypes.data, stats.ctypes.data)
     assert rc == 0
-    keys = ["samples", "ray_queries", "hit_queries", "shaded_bounces", "sphere_tests"]
+    keys = ["samples", "ray_queries", "hit_queries", "shaded_bounces", "sphere_tests", "exact_tests"]
     return rgb, dict(zip(keys, (int(x) for x in stats)))

@@ -1,0 +1,111 @@
+// microbench.hip -- issue rates of the VALU instructions the trace kernel leans on, measured on the
+// device it runs on.  Build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kIters = 4096;
+constexpr int kChains = 8;
+
+enum Op { FMA, PKFMA, MULHI, MULLO, MAD64, SQRT, RCP, RSQ, CMPSEL, PHILOX, ADD, EXP2, SINREV };
+
+template <int OP>
+__global__ __launch_bounds__(256) void bench(float * out, float seed)
+{
+  float x[kChains];
+  f2 p[kChains];
+  uint32_t u[kChains];
+  for (int i = 0; i < kChains; ++i)
+  {
+    x[i] = seed + threadIdx.x * 1e-3f + i;
+    p[i] = f2{x[i], x[i] + 1.0f};
+    u[i] = (uint32_t)(threadIdx.x * 2654435761u + i);
+  }
+  float const a = seed * 0.5f + 1.0f, b = seed * 0.25f;
+  for (int it = 0; it < kIters; ++it)
+  {
+#pragma unroll
+    for (int i = 0; i < kChains; ++i)
+    {
+      if (OP == FMA) x[i] = __builtin_fmaf(x[i], a, b);
+      if (OP == ADD) x[i] = x[i] + a;
+      if (OP == PKFMA) p[i] = __builtin_elementwise_fma(p[i], f2{a, a}, f2{b, b});
+      if (OP == MULHI) u[i] = __umulhi(u[i], 0xD2511F53u);
+      if (OP == MULLO) u[i] = u[i] * 0xCD9E8D57u + 1u;
+      if (OP == MAD64)
+      {
+        unsigned long long const m = (unsigned long long)u[i] * 0xD2511F53u;
+        u[i] = (uint32_t)(m >> 32) ^ (uint32_t)m;
+      }
+      if (OP == SQRT) x[i] = __builtin_amdgcn_sqrtf(x[i]) + a;
+      if (OP == RCP) x[i] = __builtin_amdgcn_rcpf(x[i]) + a;
+      if (OP == RSQ) x[i] = __builtin_amdgcn_rsqf(x[i]) + a;
+      if (OP == EXP2) x[i] = __builtin_amdgcn_exp2f(x[i]) * b;
+      if (OP == SINREV) x[i] = __builtin_amdgcn_sinf(x[i]) + a;
+      if (OP == CMPSEL) x[i] = (x[i] >= a && x[i] < b) ? x[i] * a : b;
+      if (OP == PHILOX)
+      {
+        uint32_t c0 = u[i], c1 = it, c2 = i, c3 = 0, k0 = threadIdx.x, k1 = 7;
+#pragma unroll
+        for (int r = 0; r < 10; ++r)
+        {
+          uint32_t const hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+          uint32_t const hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+          c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+          k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        u[i] = c0 ^ c1 ^ c2 ^ c3;
+      }
+    }
+  }
+  float acc = 0.0f;
+  for (int i = 0; i < kChains; ++i)
+    acc += x[i] + p[i].x + p[i].y + (float)u[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int OP>
+void run(const char * name, double ops_per_call, int blocks, float * d_out)
+{
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1.5f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1.5f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  double const lane_ops = (double)blocks * 256 * kIters * kChains * ops_per_call;
+  printf("%-8s %8.3f ms  %8.2f Tlane-op/s\n", name, ms, lane_ops / (ms * 1e-3) / 1e12);
+}
+
+int main()
+{
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  printf("device %s %s CUs %d clock %d kHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
+  int const blocks = prop.multiProcessorCount * 8;
+  float * d_out;
+  hipMalloc(&d_out, (size_t)blocks * 256 * sizeof(float));
+  run<FMA>("fma", 1, blocks, d_out);
+  run<ADD>("add", 1, blocks, d_out);
+  run<PKFMA>("pk_fma", 2, blocks, d_out);
+  run<MULHI>("mul_hi", 1, blocks, d_out);
+  run<MULLO>("mul_lo", 1, blocks, d_out);
+  run<MAD64>("mad64", 1, blocks, d_out);
+  run<SQRT>("sqrt+add", 1, blocks, d_out);
+  run<RCP>("rcp+add", 1, blocks, d_out);
+  run<RSQ>("rsq+add", 1, blocks, d_out);
+  run<EXP2>("exp2*mul", 1, blocks, d_out);
+  run<SINREV>("sin+add", 1, blocks, d_out);
+  run<CMPSEL>("cmpsel", 1, blocks, d_out);
+  run<PHILOX>("philox", 1, blocks, d_out);
+  hipFree(d_out);
+  return 0;
+}

@@ -1,0 +1,23 @@
+"""Renders one frame on the HIP backend and prints its counters; the command rocprofv3 wraps.
+
+python tools/render_once.py DEMO WIDTH HEIGHT SAMPLES_IN_ROW [REPEAT] [SPHERES]
+"""
+import sys
+
+sys.path.insert(0, ".")
+from rt_amd import ffi  # noqa: E402
+
+demo, w, h, s = (int(x) for x in sys.argv[1:5])
+repeat = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+spheres = int(sys.argv[6]) if len(sys.argv) > 6 else 10000
+r = ffi.HipRenderer(0)
+sc = ffi.Scene.demo(demo, 1, spheres)
+p = ffi.params(w, h, s, seed=1)
+for _ in range(repeat):
+    out, st = r.render(sc, p)
+d = st.as_dict()
+flop = 20.0 * sc.sphere_count * d["ray_queries"] + 30.0 * d["hit_queries"] + 250.0 * d["shaded_bounces"]
+print(d)
+print("kernel %.3f ms  %.1f Msamples/s  %.2f TFLOP/s algorithmic  mean %.5f" %
+      (d["kernel_ms"], d["samples"] / d["kernel_ms"] / 1e3, flop / d["kernel_ms"] / 1e9, float(out.mean())))
+r.close()
