@@ -12,9 +12,11 @@
  *     (ray_tracing/frame.hpp:21) as DemoFrameCUDA hands it over (rt_cuda/demo_frame_cuda.cpp:39,146).
  *   - Device sum buffers are float[3 * height * width]: three planes (R, G, B) of un-normalised
  *     per-pixel sums; rt_hip_resolve_device turns them into the interleaved image.
- *   - A trace can be restricted to a slice of the sample space: sample s of pixel p belongs to
- *     slice (s + p) % slice_count.  The sums of all slices add up to the whole frame, which is how
- *     one frame is sharded over several GPUs (one process per GPU; the caller reduces the planes).
+ *   - The unit of work is one sub-sample column: the samples_in_row samples (sx, 0..S-1) of one pixel
+ *     (the inner loop of ray_tracing/frame.cpp:59-66).  A trace can be restricted to a slice of the
+ *     sample space: column sx of pixel p belongs to slice (p * S + sx) % slice_count.  The sums of all
+ *     slices add up to the whole frame, which is how one frame is sharded over several GPUs (one
+ *     process per GPU; the caller reduces the planes).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -93,6 +95,8 @@ typedef struct
   uint64_t shaded_bounces; /* hits that ran direct light + specular */
   uint64_t sphere_tests;   /* ray-sphere filter tests executed (every traced ray against every sphere) */
   uint64_t exact_tests;    /* candidates the filter let through, intersected exactly */
+  uint64_t lane_trips;     /* trips round the kernel's main loop, summed over lanes (busy or idle) */
+  uint64_t lane_rounds;    /* primary-ray rounds inside those trips, summed over lanes (busy or idle) */
   float kernel_ms;         /* device time of the trace kernel, HIP events on the launch stream; 0 if not measured */
   uint32_t reserved;
 } rt_hip_stats;
@@ -148,8 +152,8 @@ int rt_hip_job_cancel(rt_hip_job * job);
 /* Device-resident form of the same frame, for callers that own device memory and a stream (multi-GPU
  * drivers, benchmarks): traces the requested slice into d_sum_planes (float[3*h*w], device memory, fully
  * overwritten) on `stream` (a hipStream_t passed as void*; NULL = the default stream), asynchronously.
- * d_stats (device memory, may be NULL) receives an rt_hip_stats with the counters of this call
- * (kernel_ms is left 0). */
+ * d_stats (device memory, 128 bytes, may be NULL) receives the eight uint64 counters of rt_hip_stats for
+ * this call, in declaration order. */
 int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera,
                         const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
                         void * stream);

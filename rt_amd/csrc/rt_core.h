@@ -194,14 +194,16 @@ struct TraceArgs
   uint32_t width, height, s_row, s_count;  // s_count = s_row * s_row
   uint32_t flags, seed, max_depth, slice_index, slice_count;
   // outputs
-  float * planes;             // 3 planes of width*height un-normalised sums
-  uint32_t * queue_counter;   // next pixel to hand out
+  float * partial;            // 3 planes of n_items column sums: partial[c * n_items + pixel * s_row + sx]
+  uint32_t n_items;           // width * height * s_row
+  uint32_t * queue_counter;   // next work item of this slice to hand out
   unsigned long long * stats; // counters, see rt_hip.hip
 };
 
 struct LaneCounters
 {
   uint32_t samples, queries, hits, shaded, filter_tests, exact_tests;
+  uint32_t trips, rounds;  // loop trips and stage-P rounds this lane sat through, busy or not
 };
 
 // The filter.  With d = C - O and unit D, the ray can hit the sphere in front of O only if
@@ -237,12 +239,14 @@ RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float 
 // Per-lane state.
 struct Lane
 {
-  // pixel being accumulated
+  // work item being accumulated: sub-sample column sx of one pixel (its s_row samples sy = 0..s_row-1)
+  uint32_t item;    // pixel * s_row + sx
   uint32_t pixel;
-  uint32_t s_next;  // next owned sample index of the pixel (>= s_count: none left)
-  float dxp, dyp;   // dx, dy of the pixel's top-left corner (ray_tracing/frame.cpp:49,52)
+  uint32_t sx;
+  uint32_t sy;      // next sample of the column (>= s_row: none left)
+  float sdx, dyp;   // sdx of the column, dy of the pixel (ray_tracing/frame.cpp:49,52,58)
   f3 sum;
-  bool alive, need_pixel;
+  bool alive, need_item;
   // current path
   uint32_t sample;  // sample index (RNG key)
   uint32_t depth;   // entries pushed so far ("scatterResultsCount")
@@ -258,26 +262,27 @@ struct Lane
   int nx_i;  // nearest hit of the scattered ray (found during the first light's pass)
 };
 
-// Frame::ForEachRayImpl, ray_tracing/frame.cpp:58-62: direction of sub-sample `sample` = sx * S + sy.
-RT_FN f3 primary_dir(const TraceArgs & A, float dxp, float dyp, uint32_t sample)
+// Frame::ForEachRayImpl, ray_tracing/frame.cpp:61-62: direction of sub-sample (sx, sy) given the column's sdx.
+RT_FN f3 primary_dir(const TraceArgs & A, float sdx, float dyp, uint32_t sy)
 {
-  uint32_t const sx = sample / A.s_row;
-  uint32_t const sy = sample - sx * A.s_row;
-  float const sdx = dxp + A.cell_x * (float)sx / (float)A.s_row;
   float const sdy = dyp - A.cell_y * (float)sy / (float)A.s_row;
   return normalize3((A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * sdx);
 }
 
-RT_FN void begin_pixel(const TraceArgs & A, Lane & L, uint32_t pixel)
+RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
 {
+  uint32_t const pixel = item / A.s_row;
+  uint32_t const sx = item - pixel * A.s_row;
   uint32_t const y = pixel / A.width;
   uint32_t const x = pixel - y * A.width;
+  L.item = item;
   L.pixel = pixel;
-  L.dyp = (-2.0f * (float)y / (float)A.height + 1.0f) * A.dh;
-  L.dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;
+  L.sx = sx;
+  L.sy = 0;
+  L.dyp = (-2.0f * (float)y / (float)A.height + 1.0f) * A.dh;        // frame.cpp:49
+  float const dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;  // frame.cpp:52
+  L.sdx = dxp + A.cell_x * (float)sx / (float)A.s_row;                 // frame.cpp:58
   L.sum = mk3(0.0f, 0.0f, 0.0f);
-  uint32_t const g = A.slice_count;
-  L.s_next = (A.slice_index + g - pixel % g) % g;  // first sample s with (s + pixel) % g == slice_index
 }
 
 // Material::Scatter for the three materials, ray_tracing/default_materials.cpp:11-67.
@@ -435,7 +440,7 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //                     sphere tiles are re-staged inside the loop)
 //   count(p)          number of such lanes for which p holds
 //   any_wave(p)       true if p holds for any lane of the wave
-//   fetch_pixel(need) hands a fresh pixel index to each lane that asks (RT_INVALID when the frame is used up)
+//   fetch_item(need)  hands a fresh work item to each lane that asks (RT_INVALID when the slice is used up)
 //   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i)
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
@@ -560,11 +565,13 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 {
   Lane L;
   L.alive = true;
-  L.need_pixel = true;
+  L.need_item = true;
   L.has_hit = false;
   L.shading = false;
+  L.item = 0;
   L.pixel = 0;
-  L.s_next = 0;
+  L.sx = 0;
+  L.sy = 0;
   L.depth = 0;
   L.sample = 0;
   L.li = 0;
@@ -575,50 +582,49 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
   L.m_refraction = 0.0f;
   L.s_a = 1.0f;
   L.sum = L.hp = L.hn = L.hd = L.spec = L.diffuse = L.m_albedo = L.sdir = mk3(0.0f, 0.0f, 0.0f);
-  L.dxp = L.dyp = 0.0f;
+  L.sdx = L.dyp = 0.0f;
   bool const deterministic = (A.flags & RT_FLAG_DETERMINISTIC) != 0u;
-  uint32_t const np = A.width * A.height;
 
   for (;;)
   {
+    cnt.trips += 1;
     // ================= stage P: primary rays for lanes with nothing to shade =================
     for (;;)
     {
+      cnt.rounds += 1;
       bool need = L.alive && !L.has_hit && !L.shading;
-      // Pixel complete: one plain store per plane, each pixel written by exactly one lane.
-      if (need && !L.need_pixel && L.s_next >= A.s_count)
+      // Column complete: one plain store per plane; every item is written by exactly one lane.
+      if (need && !L.need_item && L.sy >= A.s_row)
       {
-        A.planes[L.pixel] = L.sum.x;
-        A.planes[np + L.pixel] = L.sum.y;
-        A.planes[2u * np + L.pixel] = L.sum.z;
-        L.need_pixel = true;
+        A.partial[L.item] = L.sum.x;
+        A.partial[A.n_items + L.item] = L.sum.y;
+        A.partial[2u * A.n_items + L.item] = L.sum.z;
+        L.need_item = true;
       }
-      bool const ask = need && L.need_pixel;
+      bool const ask = need && L.need_item;
       if (env.any(ask))
       {
-        uint32_t const p = env.fetch_pixel(ask);
+        uint32_t const q = env.fetch_item(ask);
         if (ask)
         {
-          if (p == RT_INVALID)
+          if (q == RT_INVALID)
             L.alive = false;
           else
           {
-            begin_pixel(A, L, p);
-            L.need_pixel = false;
+            begin_item(A, L, q);
+            L.need_item = false;
           }
         }
       }
-      need = need && L.alive;
-      // A pixel without owned samples (more slices than samples) is stored as zeros on the next round.
-      bool const active = need && L.s_next < A.s_count;
+      bool const active = need && L.alive;
       if (env.any(active))
       {
-        uint32_t const s = L.s_next;
+        uint32_t const s = L.sx * A.s_row + L.sy;
         f3 d = mk3(0.0f, 0.0f, 1.0f);
         if (active)
         {
-          d = primary_dir(A, L.dxp, L.dyp, s);
-          L.s_next += A.slice_count;
+          d = primary_dir(A, L.sdx, L.dyp, L.sy);
+          L.sy += 1;
         }
         float const a = dot3(d, d);
         float t;

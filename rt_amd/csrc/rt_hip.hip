@@ -7,8 +7,9 @@
 //                        count).  Waves never wait for each other.
 //   trace_kernel<true>   the same loop for larger scenes: the block re-stages the spheres through LDS in
 //                        tiles of kTileSpheres inside every ray pass, so its waves stay in step.
+//   colsum_kernel        accumulate pass: per pixel, the column sums of the slice -> planar pixel sums.
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
-//                        16 bytes per lane per access; the only HBM-bound pass.
+//                        16 bytes per lane per access.  These two are the HBM-bound passes.
 //
 //   camtab_kernel        per-frame table of the primary-ray filter, one entry per sphere.
 //
@@ -36,24 +37,52 @@ constexpr int kBlock = 256;               // 4 waves
 constexpr int kWavesPerSimd = 3;          // blocks per CU the register budget is sized for
 constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS whole (48 B per sphere)
 constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
-constexpr uint32_t kStatsWords = 6;
+constexpr uint32_t kStatsWords = 8;
 
 // ---------------------------------------------------------------- device side
 
-// One atomic per wave hands consecutive pixels to the lanes that asked.
-__device__ __forceinline__ uint32_t wave_fetch_pixel(uint32_t * counter, uint32_t total_pixels, bool need)
+// Work items come from one frame-wide counter, but a wave only touches it once per kItemBatch items: it
+// reserves a batch and then serves its lanes from that pool with a ballot and a prefix count (a single
+// counter word sustains well under a hundred dequeues per microsecond, far fewer than the waves ask for).
+// The k-th item of slice r out of g is r + g * k.
+constexpr uint32_t kItemBatch = 64;
+
+struct ItemPool
 {
-  unsigned long long const mask = __ballot(need);
-  uint32_t const lane = __lane_id();
-  int const leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (need && (int)lane == leader)
-    base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader < 0 ? 0 : leader);
-  uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  uint32_t const p = base + rank;
-  return (need && p < total_pixels) ? p : RT_INVALID;
-}
+  uint32_t next = 0, end = 0;  // wave-uniform
+
+  __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need)
+  {
+    uint32_t result = RT_INVALID;
+    uint32_t const lane = __lane_id();
+    for (;;)
+    {
+      unsigned long long const mask = __ballot(need);
+      if (mask == 0ull)
+        break;
+      if (next == end)
+      {
+        uint32_t base = 0;
+        if (lane == 0)
+          base = atomicAdd(A.queue_counter, kItemBatch);
+        next = __builtin_amdgcn_readfirstlane(base);
+        end = next + kItemBatch;
+      }
+      uint32_t const avail = end - next;
+      uint32_t const wanted = (uint32_t)__popcll(mask);
+      uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (need && rank < avail)
+      {
+        unsigned long long const q = (unsigned long long)A.slice_index +
+                                     (unsigned long long)A.slice_count * (unsigned long long)(next + rank);
+        result = q < (unsigned long long)A.n_items ? (uint32_t)q : RT_INVALID;
+        need = false;
+      }
+      next += wanted < avail ? wanted : avail;
+    }
+    return result;
+  }
+};
 
 // The whole scene is resident in LDS; waves never wait for each other.
 struct WaveEnv
@@ -62,15 +91,12 @@ struct WaveEnv
   const f4 * filt;   // LDS: n_padded filter records
   const f4 * cam;    // LDS: n_padded camera-table records
   const f4 * exact;  // LDS: n_padded exact records
-  uint32_t total_pixels;
+  ItemPool pool;
 
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
-  __device__ __forceinline__ uint32_t fetch_pixel(bool need) const
-  {
-    return wave_fetch_pixel(A.queue_counter, total_pixels, need);
-  }
+  __device__ __forceinline__ uint32_t fetch_item(bool need) { return pool.fetch(A, need); }
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ uint32_t tiles() const { return 1u; }
@@ -85,15 +111,12 @@ struct BlockEnv
 {
   const TraceArgs & A;
   f4 * tile;  // LDS: kTileSpheres entries
-  uint32_t total_pixels;
+  ItemPool pool;
 
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
-  __device__ __forceinline__ uint32_t fetch_pixel(bool need) const
-  {
-    return wave_fetch_pixel(A.queue_counter, total_pixels, need);
-  }
+  __device__ __forceinline__ uint32_t fetch_item(bool need) { return pool.fetch(A, need); }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + kTileSpheres - 1u) / kTileSpheres; }
@@ -126,12 +149,10 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
   extern __shared__ __align__(16) unsigned char lds_raw[];
   f4 * stack = reinterpret_cast<f4 *>(lds_raw);  // [RT_MAX_DEPTH][kBlock]
   f4 * sph = stack + RT_MAX_DEPTH * kBlock;      // resident scene, or the staging tile
-  uint32_t const total_pixels = A.width * A.height;
-
-  LaneCounters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
+  LaneCounters cnt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   if constexpr (kTiled)
   {
-    BlockEnv env{A, sph, total_pixels};
+    BlockEnv env{A, sph, ItemPool()};
     trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
       exact[i] = A.spheres[i];
     }
     __syncthreads();
-    WaveEnv env{A, sph, cam, exact, total_pixels};
+    WaveEnv env{A, sph, cam, exact, ItemPool()};
     trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
 
@@ -156,6 +177,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
   uint32_t const c3 = wave_sum(cnt.shaded);
   uint32_t const c4 = wave_sum(cnt.filter_tests);
   uint32_t const c5 = wave_sum(cnt.exact_tests);
+  uint32_t const c6 = wave_sum(cnt.trips);
+  uint32_t const c7 = wave_sum(cnt.rounds);
   if (A.stats != nullptr && __lane_id() == 0)
   {
     atomicAdd(&A.stats[0], (unsigned long long)c0);
@@ -164,6 +187,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
     atomicAdd(&A.stats[3], (unsigned long long)c3);
     atomicAdd(&A.stats[4], (unsigned long long)c4);
     atomicAdd(&A.stats[5], (unsigned long long)c5);
+    atomicAdd(&A.stats[6], (unsigned long long)c6);
+    atomicAdd(&A.stats[7], (unsigned long long)c7);
   }
 }
 
@@ -182,6 +207,33 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
   e.z = dz;
   e.w = filter_bound(dx, dy, dz, s.w);
   camtab[i] = e;
+}
+
+// The accumulate pass: per pixel and plane, the column sums this slice owns are added in increasing sx
+// (the order Frame::ForEachRayImpl adds its outer loop, ray_tracing/frame.cpp:56).  partial: 3 planes of
+// n * s_row floats; planes: 3 planes of n floats.  One lane per pixel; a pixel's columns are contiguous.
+__global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ partial, float * __restrict__ planes,
+                                                     uint32_t n, uint32_t s_row, uint32_t slice_index,
+                                                     uint32_t slice_count)
+{
+  uint32_t const stride = gridDim.x * blockDim.x;
+  size_t const n_items = (size_t)n * s_row;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
+  {
+    size_t const first = (size_t)p * s_row;
+    // first owned column: smallest sx with (first + sx) % slice_count == slice_index
+    uint32_t const sx0 = (uint32_t)((slice_index + slice_count - (uint32_t)(first % slice_count)) % slice_count);
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t sx = sx0; sx < s_row; sx += slice_count)
+    {
+      r += partial[first + sx];
+      g += partial[n_items + first + sx];
+      b += partial[2u * n_items + first + sx];
+    }
+    planes[p] = r;
+    planes[n + p] = g;
+    planes[2u * (size_t)n + p] = b;
+  }
 }
 
 // planes: 3 x n floats; rgb: n x 3 floats.  Each lane takes 4 pixels: three 16-byte loads, three 16-byte
@@ -244,6 +296,8 @@ struct Library
   char name[256] = {0};
   hipStream_t stream = nullptr;       // trace launches of the job API
   hipStream_t copy_stream = nullptr;  // snapshots, so they never queue behind a running trace
+  float * workspace = nullptr;        // column sums of rt_hip_trace_device calls, grown on demand
+  size_t workspace_bytes = 0;
 };
 Library g_lib;
 
@@ -263,6 +317,7 @@ struct rt_hip_scene
 struct rt_hip_job
 {
   rt_hip_trace_params params;
+  float * d_partial = nullptr;  // 3 * width * height * samples_in_row column sums
   float * d_planes = nullptr;
   float * d_rgb = nullptr;
   unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
@@ -283,7 +338,7 @@ size_t lds_bytes(uint32_t n_padded)
 
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
 // more lanes than pixels.
-int persistent_blocks(uint32_t n_padded, uint32_t pixels)
+int persistent_blocks(uint32_t n_padded, unsigned long long items)
 {
   int per_cu = 0;
   hipError_t e;
@@ -294,7 +349,7 @@ int persistent_blocks(uint32_t n_padded, uint32_t pixels)
   if (e != hipSuccess || per_cu < 1)
     per_cu = 1;
   long long blocks = (long long)per_cu * std::max(g_lib.compute_units, 1);
-  long long const needed = ((long long)pixels + kBlock - 1) / kBlock;
+  long long const needed = ((long long)items + kBlock - 1) / kBlock;
   blocks = std::max(1ll, std::min(blocks, needed));
   return (int)blocks;
 }
@@ -311,17 +366,19 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
     return fail(RT_HIP_ERR_INVALID, "frame larger than 2^30 pixels");
   if (p->samples_in_row > 4096u)
     return fail(RT_HIP_ERR_INVALID, "samples_in_row larger than 4096");
+  if ((unsigned long long)p->width * p->height * p->samples_in_row >= 0xF0000000ull)
+    return fail(RT_HIP_ERR_INVALID, "width * height * samples_in_row must stay below 0xF0000000");
   if (p->slice_count > 1u && p->slice_index >= p->slice_count)
     return fail(RT_HIP_ERR_INVALID, "slice_index must be below slice_count");
   return RT_HIP_OK;
 }
 
 // Enqueues, on `stream`: counter reset, the camera table for this frame's camera, the trace kernel.
-// d_stats points at kStatsWords counters followed by the queue counter (one 8-byte slot).  When events are
-// given they are recorded directly around the trace kernel.  The camera table lives in the scene, so one
-// scene carries one trace at a time.
+// d_partial receives the column sums of this slice; d_stats points at kStatsWords counters followed by the
+// queue counter (one 8-byte slot).  When events are given they are recorded directly around the trace
+// kernel.  The camera table lives in the scene, so one scene carries one trace at a time.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
-                 float * d_planes, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
+                 float * d_partial, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
                  hipEvent_t ev_start, hipEvent_t ev_stop)
 {
   TraceArgs a;
@@ -337,7 +394,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.n_padded = scene->n_padded;
   a.n_materials = scene->n_materials;
   a.n_lights = scene->n_lights;
-  a.planes = d_planes;
+  a.partial = d_partial;
+  a.n_items = p->width * p->height * p->samples_in_row;
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
 
@@ -350,8 +408,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     RT_CHECK(hipGetLastError());
   }
   bool const tiled = is_tiled(scene->n_padded);
-  uint32_t const pixels = p->width * p->height;
-  int const blocks = persistent_blocks(scene->n_padded, pixels);
+  unsigned long long const my_items = ((unsigned long long)a.n_items + a.slice_count - 1u) / a.slice_count;
+  int const blocks = persistent_blocks(scene->n_padded, my_items);
   size_t const lds = lds_bytes(scene->n_padded);
   if (ev_start)
     RT_CHECK(hipEventRecord(ev_start, stream));
@@ -363,6 +421,22 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   if (ev_stop)
     RT_CHECK(hipEventRecord(ev_stop, stream));
   return RT_HIP_OK;
+}
+
+int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream)
+{
+  uint32_t const n = p->width * p->height;
+  uint32_t const g = p->slice_count ? p->slice_count : 1u;
+  int const blocks = (int)std::min<uint32_t>((n + 255u) / 256u, 256u * 8u);
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row,
+                     p->slice_index % g, g);
+  RT_CHECK(hipGetLastError());
+  return RT_HIP_OK;
+}
+
+size_t partial_bytes(const rt_hip_trace_params * p)
+{
+  return 3 * sizeof(float) * (size_t)p->width * p->height * p->samples_in_row;
 }
 
 int launch_resolve(const float * d_planes, float * d_rgb, uint32_t width, uint32_t height, uint32_t s_row,
@@ -385,12 +459,15 @@ void read_stats(const unsigned long long * h, rt_hip_stats * out)
   out->shaded_bounces = h[3];
   out->sphere_tests = h[4];
   out->exact_tests = h[5];
+  out->lane_trips = h[6];
+  out->lane_rounds = h[7];
 }
 
 void free_job(rt_hip_job * job)
 {
   if (job == nullptr)
     return;
+  if (job->d_partial) (void)hipFree(job->d_partial);
   if (job->d_planes) (void)hipFree(job->d_planes);
   if (job->d_rgb) (void)hipFree(job->d_rgb);
   if (job->d_stats) (void)hipFree(job->d_stats);
@@ -446,6 +523,9 @@ void rt_hip_shutdown(void)
   (void)hipStreamSynchronize(g_lib.copy_stream);
   (void)hipStreamDestroy(g_lib.stream);
   (void)hipStreamDestroy(g_lib.copy_stream);
+  if (g_lib.workspace) (void)hipFree(g_lib.workspace);
+  g_lib.workspace = nullptr;
+  g_lib.workspace_bytes = 0;
   g_lib.stream = nullptr;
   g_lib.copy_stream = nullptr;
   g_lib.ready = false;
@@ -553,19 +633,20 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
     return fail(RT_HIP_ERR_DEVICE, "out of host memory");
   job->params = *params;
   size_t const pixels = (size_t)params->width * params->height;
-  hipError_t e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
+  hipError_t e = hipMalloc((void **)&job->d_partial, partial_bytes(params));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_rgb, 3 * pixels * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
   if (e == hipSuccess) e = hipEventCreate(&job->start);
   if (e == hipSuccess) e = hipEventCreate(&job->stop);
-  // Unfinished pixels read as black in snapshots.
-  if (e == hipSuccess) e = hipMemsetAsync(job->d_planes, 0, 3 * pixels * sizeof(float), g_lib.stream);
+  // Unfinished columns read as black in snapshots.
+  if (e == hipSuccess) e = hipMemsetAsync(job->d_partial, 0, partial_bytes(params), g_lib.stream);
   if (e != hipSuccess)
   {
     free_job(job);
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   }
-  rc = launch_trace(scene, camera, params, job->d_planes, job->d_stats, true, g_lib.stream, job->start,
+  rc = launch_trace(scene, camera, params, job->d_partial, job->d_stats, true, g_lib.stream, job->start,
                     job->stop);
   if (rc != RT_HIP_OK)
   {
@@ -595,7 +676,11 @@ int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
     return fail(RT_HIP_ERR_INVALID, "null argument");
   size_t const pixels = (size_t)job->params.width * job->params.height;
   std::vector<float> planes(3 * pixels);
-  // A copy on its own stream: it runs beside the trace kernel and never waits for it.
+  // Accumulate + copy on their own stream: they run beside the trace kernel and never wait for it.  Columns
+  // the trace has not finished yet still hold the zeros they were cleared to.
+  int const rc = launch_colsum(job->d_partial, job->d_planes, &job->params, g_lib.copy_stream);
+  if (rc != RT_HIP_OK)
+    return rc;
   RT_CHECK(hipMemcpyAsync(planes.data(), job->d_planes, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost,
                           g_lib.copy_stream));
   RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
@@ -614,7 +699,7 @@ int rt_hip_job_cancel(rt_hip_job * job)
   if (job == nullptr)
     return fail(RT_HIP_ERR_INVALID, "null job");
   job->cancelled = true;
-  // Push the pixel queue past the end of the frame: lanes finish the pixel they hold and stop.
+  // Push the work queue past the end of the frame: lanes finish the column they hold and stop.
   RT_CHECK(hipMemsetAsync(job->d_stats + kStatsWords, 0x7f, sizeof(uint32_t), g_lib.copy_stream));
   RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
   return RT_HIP_OK;
@@ -631,8 +716,10 @@ int rt_hip_job_finish(rt_hip_job * job, float * rgb, rt_hip_stats * stats)
   size_t const pixels = (size_t)job->params.width * job->params.height;
   if (rc == RT_HIP_OK && rgb != nullptr)
   {
-    rc = launch_resolve(job->d_planes, job->d_rgb, job->params.width, job->params.height,
-                        job->params.samples_in_row, g_lib.stream);
+    rc = launch_colsum(job->d_partial, job->d_planes, &job->params, g_lib.stream);
+    if (rc == RT_HIP_OK)
+      rc = launch_resolve(job->d_planes, job->d_rgb, job->params.width, job->params.height,
+                          job->params.samples_in_row, g_lib.stream);
     if (rc == RT_HIP_OK)
     {
       e = hipMemcpyAsync(rgb, job->d_rgb, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost, g_lib.stream);
@@ -678,11 +765,28 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
   if (st == nullptr)
   {
     if (s_scratch == nullptr)
-      RT_CHECK(hipMalloc((void **)&s_scratch, 64));
+      RT_CHECK(hipMalloc((void **)&s_scratch, sizeof(unsigned long long) * (kStatsWords + 1)));
     st = s_scratch;
   }
-  return launch_trace(scene, camera, params, d_sum_planes, st, d_stats != nullptr,
-                      static_cast<hipStream_t>(stream), nullptr, nullptr);
+  // Column sums go to a library workspace that only ever grows; the planes are accumulated from it.
+  size_t const need = partial_bytes(params);
+  if (g_lib.workspace_bytes < need)
+  {
+    if (g_lib.workspace != nullptr)
+    {
+      RT_CHECK(hipDeviceSynchronize());
+      (void)hipFree(g_lib.workspace);
+      g_lib.workspace = nullptr;
+      g_lib.workspace_bytes = 0;
+    }
+    RT_CHECK(hipMalloc((void **)&g_lib.workspace, need));
+    g_lib.workspace_bytes = need;
+  }
+  hipStream_t const hs = static_cast<hipStream_t>(stream);
+  int rc2 = launch_trace(scene, camera, params, g_lib.workspace, st, d_stats != nullptr, hs, nullptr, nullptr);
+  if (rc2 == RT_HIP_OK)
+    rc2 = launch_colsum(g_lib.workspace, d_sum_planes, params, hs);
+  return rc2;
 }
 
 int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t width, uint32_t height,
@@ -704,11 +808,10 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
     return rc;
   if (launches == 0 || out_avg_ms == nullptr)
     return fail(RT_HIP_ERR_INVALID, "bad argument");
-  size_t const pixels = (size_t)params->width * params->height;
-  float * d_planes = nullptr;
+  float * d_planes = nullptr;  // column sums
   unsigned long long * d_stats = nullptr;
   hipEvent_t start = nullptr, stop = nullptr;
-  hipError_t e = hipMalloc((void **)&d_planes, 3 * pixels * sizeof(float));
+  hipError_t e = hipMalloc((void **)&d_planes, partial_bytes(params));
   if (e == hipSuccess) e = hipMalloc((void **)&d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
   if (e == hipSuccess) e = hipEventCreate(&start);
   if (e == hipSuccess) e = hipEventCreate(&stop);

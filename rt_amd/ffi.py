@@ -54,6 +54,8 @@ class Stats(C.Structure):
         ("shaded_bounces", C.c_uint64),
         ("sphere_tests", C.c_uint64),
         ("exact_tests", C.c_uint64),
+        ("lane_trips", C.c_uint64),
+        ("lane_rounds", C.c_uint64),
         ("kernel_ms", C.c_float),
         ("reserved", C.c_uint32),
     ]

@@ -20,12 +20,12 @@ struct HostEnv
   bool any(bool p) { return p; }
   int count(bool p) { return p ? 1 : 0; }
   bool any_wave(bool p) { return p; }
-  uint32_t fetch_pixel(bool need)
+  uint32_t fetch_item(bool need)
   {
     if (!need)
       return rtc::RT_INVALID;
-    uint32_t const p = next++;
-    return p < total ? p : rtc::RT_INVALID;
+    unsigned long long const q = A.slice_index + (unsigned long long)A.slice_count * next++;
+    return q < total ? (uint32_t)q : rtc::RT_INVALID;
   }
   rtc::f4 sphere(int i) const { return A.spheres[i]; }
   uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -71,20 +71,29 @@ extern "C" int emu_render(const float * centers_radii, const uint32_t * material
   a.n_materials = m;
   a.n_lights = l;
   uint32_t const np = p->width * p->height;
-  std::vector<float> planes(3u * (size_t)np, 0.0f);
-  a.planes = planes.data();
+  uint32_t const s_row = p->samples_in_row;
+  a.n_items = np * s_row;
+  std::vector<float> partial(3u * (size_t)a.n_items, 0.0f);
+  a.partial = partial.data();
   a.queue_counter = nullptr;
   a.stats = nullptr;
 
   std::vector<rtc::f4> stack(rtc::RT_MAX_DEPTH);
   rtc::LaneCounters cnt{};
-  HostEnv env{a, np, tile_size ? tile_size : (padded ? padded : 4u)};
+  HostEnv env{a, a.n_items, tile_size ? tile_size : (padded ? padded : 4u)};
   rtc::trace_loop(a, env, stack.data(), 1u, cnt);
 
-  float const inv = 1.0f / static_cast<float>(p->samples_in_row * p->samples_in_row);
+  // accumulate (owned columns in increasing sx) + resolve, as colsum_kernel and resolve_kernel do
+  float const inv = 1.0f / static_cast<float>(s_row * s_row);
   for (uint32_t i = 0; i < np; ++i)
     for (uint32_t c = 0; c < 3; ++c)
-      rgb[3u * (size_t)i + c] = planes[(size_t)c * np + i] * inv;
+    {
+      float sum = 0.0f;
+      for (uint32_t sx = 0; sx < s_row; ++sx)
+        if (((unsigned long long)i * s_row + sx) % a.slice_count == a.slice_index)
+          sum += partial[(size_t)c * a.n_items + (size_t)i * s_row + sx];
+      rgb[3u * (size_t)i + c] = sum * inv;
+    }
   if (stats6)
   {
     stats6[0] = cnt.samples;

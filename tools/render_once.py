@@ -1,6 +1,6 @@
 """Renders one frame on the HIP backend and prints its counters; the command rocprofv3 wraps.
 
-python tools/render_once.py DEMO WIDTH HEIGHT SAMPLES_IN_ROW [REPEAT] [SPHERES]
+python tools/render_once.py DEMO WIDTH HEIGHT SAMPLES_IN_ROW [REPEAT] [SPHERES] [FLAGS] [MAX_DEPTH]
 """
 import sys
 
@@ -10,9 +10,11 @@ from rt_amd import ffi  # noqa: E402
 demo, w, h, s = (int(x) for x in sys.argv[1:5])
 repeat = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 spheres = int(sys.argv[6]) if len(sys.argv) > 6 else 10000
+flags = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+depth = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 r = ffi.HipRenderer(0)
 sc = ffi.Scene.demo(demo, 1, spheres)
-p = ffi.params(w, h, s, seed=1)
+p = ffi.params(w, h, s, seed=1, flags=flags, max_depth=depth)
 for _ in range(repeat):
     out, st = r.render(sc, p)
 d = st.as_dict()
