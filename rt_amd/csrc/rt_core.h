@@ -100,10 +100,48 @@ RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 RT_FN int hw_clz(uint32_t x) { return __clz((int)x); }
 RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
-// mask = 2 * mask + (x >= bound): a compare into VCC and an add-with-carry that shifts it in.
-RT_FN void push_ge(uint32_t & mask, float x, float bound)
+// mask[r] = 2 * mask[r] + (x[r] >= bound) for six rays: six compares into six SGPR pairs, then six
+// add-with-carry that shift the results in.  Written as one block because gfx950 wants two wait states
+// between a VALU write of a lane mask and a VALU read of it, and the compiler pads nothing inside an asm
+// statement: here every add-with-carry reads a mask written six instructions earlier.  For the same reason
+// `bound` must not come straight out of a transcendental instruction (one wait state): callers pass it
+// through an ordinary VALU instruction first.
+RT_FN void push_ge6(uint32_t (&mask)[RT_RAYS], const float (&x)[RT_RAYS], float bound)
 {
-  asm("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(x), "v"(bound) : "vcc");
+  unsigned long long c0, c1, c2, c3, c4, c5;
+  asm("v_cmp_ge_f32_e64 %[c0], %[x0], %[b]\n\t"
+      "v_cmp_ge_f32_e64 %[c1], %[x1], %[b]\n\t"
+      "v_cmp_ge_f32_e64 %[c2], %[x2], %[b]\n\t"
+      "v_cmp_ge_f32_e64 %[c3], %[x3], %[b]\n\t"
+      "v_cmp_ge_f32_e64 %[c4], %[x4], %[b]\n\t"
+      "v_cmp_ge_f32_e64 %[c5], %[x5], %[b]\n\t"
+      "v_addc_co_u32_e64 %[m0], %[c0], %[m0], %[m0], %[c0]\n\t"
+      "v_addc_co_u32_e64 %[m1], %[c1], %[m1], %[m1], %[c1]\n\t"
+      "v_addc_co_u32_e64 %[m2], %[c2], %[m2], %[m2], %[c2]\n\t"
+      "v_addc_co_u32_e64 %[m3], %[c3], %[m3], %[m3], %[c3]\n\t"
+      "v_addc_co_u32_e64 %[m4], %[c4], %[m4], %[m4], %[c4]\n\t"
+      "v_addc_co_u32_e64 %[m5], %[c5], %[m5], %[m5], %[c5]"
+      : [m0] "+v"(mask[0]), [m1] "+v"(mask[1]), [m2] "+v"(mask[2]), [m3] "+v"(mask[3]), [m4] "+v"(mask[4]),
+        [m5] "+v"(mask[5]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4),
+        [c5] "=&s"(c5)
+      : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]),
+        [b] "v"(bound));
+}
+// The same for four table entries of one ray: mask = 16 * mask + the four results, first entry highest.
+RT_FN void push_ge4(uint32_t & mask, const float (&x)[4], const float (&bound)[4])
+{
+  unsigned long long c0, c1, c2, c3;
+  asm("v_cmp_ge_f32_e64 %[c0], %[x0], %[b0]\n\t"
+      "v_cmp_ge_f32_e64 %[c1], %[x1], %[b1]\n\t"
+      "v_cmp_ge_f32_e64 %[c2], %[x2], %[b2]\n\t"
+      "v_cmp_ge_f32_e64 %[c3], %[x3], %[b3]\n\t"
+      "v_addc_co_u32_e64 %[m], %[c0], %[m], %[m], %[c0]\n\t"
+      "v_addc_co_u32_e64 %[m], %[c1], %[m], %[m], %[c1]\n\t"
+      "v_addc_co_u32_e64 %[m], %[c2], %[m], %[m], %[c2]\n\t"
+      "v_addc_co_u32_e64 %[m], %[c3], %[m], %[m], %[c3]"
+      : [m] "+v"(mask), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
+      : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [b0] "v"(bound[0]), [b1] "v"(bound[1]),
+        [b2] "v"(bound[2]), [b3] "v"(bound[3]));
 }
 #else
 RT_FN float hw_sqrt(float x) { return sqrtf(x); }
@@ -122,7 +160,16 @@ RT_FN uint32_t f2u(float f)
   return u;
 }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
-RT_FN void push_ge(uint32_t & mask, float x, float bound) { mask = mask + mask + (x >= bound ? 1u : 0u); }
+RT_FN void push_ge6(uint32_t (&mask)[RT_RAYS], const float (&x)[RT_RAYS], float bound)
+{
+  for (int r = 0; r < RT_RAYS; ++r)
+    mask[r] = mask[r] + mask[r] + (x[r] >= bound ? 1u : 0u);
+}
+RT_FN void push_ge4(uint32_t & mask, const float (&x)[4], const float (&bound)[4])
+{
+  for (int u = 0; u < 4; ++u)
+    mask = mask + mask + (x[u] >= bound[u] ? 1u : 0u);
+}
 #endif
 
 // ---- exact helpers: the GLSL definitions glm follows, IEEE sqrt and division ----
@@ -187,6 +234,7 @@ struct TraceArgs
   const f4 * materials;        // n_materials x 2: (albedo rgb, roughness), (refraction, type bits, 0, 0)
   const f4 * lights;           // n_lights x 2: (direction xyz, 0), (colour rgb, 0)
   uint32_t n_spheres, n_padded, n_materials, n_lights;
+  uint32_t tile_size;          // filter records staged per tile when the scene is not resident (multiple of RT_PAD)
   // camera, precomputed on the host exactly as Frame::ForEachRayImpl does (ray_tracing/frame.cpp:33-41)
   f3 cam_pos, cam_dir, cam_right, cam_up, background;
   float znear, zfar, dw, dh, cell_x, cell_y;
@@ -197,6 +245,7 @@ struct TraceArgs
   float * partial;            // 3 planes of n_items column sums: partial[c * n_items + pixel * s_row + sx]
   uint32_t n_items;           // width * height * s_row
   uint32_t * queue_counter;   // next work item of this slice to hand out
+  const uint32_t * cancel;    // non-zero: stop handing out work (host-visible memory, read on refills only)
   unsigned long long * stats; // counters, see rt_hip.hip
 };
 
@@ -214,7 +263,8 @@ struct LaneCounters
 RT_FN float filter_bound(float dx, float dy, float dz, float r2f)
 {
   float const dd = hw_fma(dz, dz, hw_fma(dy, dy, dx * dx));
-  return hw_sqrt(hw_max(hw_fma(dd, (float)(1.0 - RT_FILTER_MARGIN), -r2f), 0.0f));
+  // sqrt of a negative number is a NaN, which max() turns into the 0 wanted for an origin inside the sphere
+  return hw_max(hw_sqrt(hw_fma(dd, (float)(1.0 - RT_FILTER_MARGIN), -r2f)), 0.0f);
 }
 
 // Sphere::TraceNearest, ray_tracing/sphere.cpp:63-81, operation for operation (a = dot(D, D) hoisted).
@@ -392,13 +442,15 @@ RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
   uint32_t mask = 0;
   for (uint32_t j = 0; j < count; j += RT_PAD)
   {
+    float x[RT_PAD], bound[RT_PAD];
 #pragma unroll
     for (uint32_t u = 0; u < RT_PAD; ++u)
     {
       f4 const e = tab[j + u];
-      float const x = hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, e.x * dir.x));
-      push_ge(mask, x, e.w);
+      x[u] = hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, e.x * dir.x));
+      bound[u] = e.w;
     }
+    push_ge4(mask, x, bound);
   }
   return mask;
 }
@@ -417,12 +469,11 @@ RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[
       f4 const s = sph[j + u];
       float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
       float const bound = filter_bound(dx, dy, dz, s.w);
+      float x[RT_RAYS];
 #pragma unroll
       for (int r = 0; r < RT_RAYS; ++r)
-      {
-        float const x = hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, dx * dir[r].x));
-        push_ge(mask[r], x, bound);
-      }
+        x[r] = hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, dx * dir[r].x));
+      push_ge6(mask, x, bound);
     }
   }
 }
@@ -482,18 +533,13 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
     cnt.filter_tests += A.n_spheres;
 }
 
+// rays_on: bit r set if ray r of this lane is to be traced.  Returns the shadow rays found occluded as bits
+// 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.
 template <class Env>
-RT_FN void trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
-                      const bool (&on)[RT_RAYS], bool (&occluded)[RT_LIGHT_SAMPLES], float & near_t,
-                      int & near_i, LaneCounters & cnt)
+RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
+                          uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
 {
-  bool live[RT_RAYS];
-#pragma unroll
-  for (int r = 0; r < RT_RAYS; ++r)
-    live[r] = on[r];
-#pragma unroll
-  for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
-    occluded[r] = false;
+  uint32_t live = rays_on;  // rays still looking for a hit
   near_i = -1;
   near_t = 0.0f;
   for (uint32_t k = 0; k < env.tiles(); ++k)
@@ -510,7 +556,7 @@ RT_FN void trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_R
 #pragma unroll
       for (int r = 0; r < RT_RAYS; ++r)
       {
-        mask[r] = live[r] ? mask[r] : 0u;
+        mask[r] = ((live >> r) & 1u) ? mask[r] : 0u;
         any_mask |= mask[r];
       }
       if (!env.any_wave(any_mask != 0u))
@@ -528,8 +574,7 @@ RT_FN void trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_R
             cnt.exact_tests += 1;
             if (exact_hit(o, dir[r], a[r], env.sphere(i), 0.001f, 1000.0f, t))
             {
-              occluded[r] = true;
-              live[r] = false;
+              live &= ~(1u << r);
               mask[r] = 0u;
             }
           }
@@ -553,11 +598,8 @@ RT_FN void trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_R
       }
     }
   }
-  uint32_t rays_on = 0;
-#pragma unroll
-  for (int r = 0; r < RT_RAYS; ++r)
-    rays_on += on[r] ? 1u : 0u;
-  cnt.filter_tests += rays_on * A.n_spheres;
+  cnt.filter_tests += (uint32_t)__builtin_popcount(rays_on) * A.n_spheres;
+  return (rays_on & ~live) & ((1u << RT_LIGHT_SAMPLES) - 1u);
 }
 
 template <class Env>
@@ -667,14 +709,13 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     // ================= stage S: shade the hits =================
     f3 dir[RT_RAYS];
     float a[RT_RAYS];
-    bool on[RT_RAYS];
+    uint32_t rays_on = 0;
     float w[RT_LIGHT_SAMPLES];
 #pragma unroll
     for (int r = 0; r < RT_RAYS; ++r)
     {
       dir[r] = mk3(0.0f, 0.0f, 1.0f);
       a[r] = 1.0f;
-      on[r] = false;
     }
 #pragma unroll
     for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
@@ -765,7 +806,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           f3 const rd = normalize3_fast(to_light + jit[j]);
           dir[j] = rd;
           a[j] = dot3(rd, rd);
-          on[j] = true;
+          rays_on |= 1u << j;
           w[j] = maxf(0.0f, dot3(rd, L.hn));
         }
       }
@@ -773,14 +814,13 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       {
         dir[RT_RAYS - 1] = L.sdir;
         a[RT_RAYS - 1] = L.s_a;
-        on[RT_RAYS - 1] = true;
+        rays_on |= 1u << (RT_RAYS - 1);
       }
     }
 
-    bool occluded[RT_LIGHT_SAMPLES];
     float near_t;
     int near_i;
-    trace_pass(A, env, L.hp, dir, a, on, occluded, near_t, near_i, cnt);
+    uint32_t const occluded = trace_pass(A, env, L.hp, dir, a, rays_on, near_t, near_i, cnt);
 
     if (in_pass)
     {
@@ -795,8 +835,9 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
         {
-          color = color + (occluded[j] ? tint : lcol) * w[j];
-          cnt.hits += occluded[j] ? 1u : 0u;
+          bool const blocked = ((occluded >> j) & 1u) != 0u;
+          color = color + (blocked ? tint : lcol) * w[j];
+          cnt.hits += blocked ? 1u : 0u;
         }
         L.diffuse = L.diffuse + color / (float)RT_LIGHT_SAMPLES;
         cnt.queries += RT_LIGHT_SAMPLES;

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,7 +65,11 @@ struct ItemPool
       {
         uint32_t base = 0;
         if (lane == 0)
-          base = atomicAdd(A.queue_counter, kItemBatch);
+        {
+          // A cancelled job stops at the next refill: the wave is sent past the end of the queue.
+          bool const cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+          base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, kItemBatch);
+        }
         next = __builtin_amdgcn_readfirstlane(base);
         end = next + kItemBatch;
       }
@@ -119,12 +124,12 @@ struct BlockEnv
   __device__ __forceinline__ uint32_t fetch_item(bool need) { return pool.fetch(A, need); }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-  __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + kTileSpheres - 1u) / kTileSpheres; }
-  __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * kTileSpheres; }
+  __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + A.tile_size - 1u) / A.tile_size; }
+  __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * A.tile_size; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t k, bool primary) const
   {
-    uint32_t const base = k * kTileSpheres;
-    uint32_t const count = min(kTileSpheres, A.n_padded - base);
+    uint32_t const base = k * A.tile_size;
+    uint32_t const count = min(A.tile_size, A.n_padded - base);
     const f4 * src = (primary ? A.camtab : A.filter) + base;
     __syncthreads();  // everyone is done with the previous tile
     for (uint32_t i = threadIdx.x; i < count; i += kBlock)
@@ -298,6 +303,7 @@ struct Library
   hipStream_t copy_stream = nullptr;  // snapshots, so they never queue behind a running trace
   float * workspace = nullptr;        // column sums of rt_hip_trace_device calls, grown on demand
   size_t workspace_bytes = 0;
+  uint32_t * never_cancel = nullptr;  // a zero word for traces that cannot be cancelled
 };
 Library g_lib;
 
@@ -322,12 +328,25 @@ struct rt_hip_job
   float * d_rgb = nullptr;
   unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
   hipEvent_t start = nullptr, stop = nullptr;
+  uint32_t * h_cancel = nullptr;  // pinned host word the kernel polls; written by rt_hip_job_cancel
   bool cancelled = false;
 };
 
 namespace
 {
-bool is_tiled(uint32_t n_padded) { return n_padded > kResidentSpheres; }
+// RT_HIP_FORCE_TILE=n (a multiple of 4, at most kTileSpheres) makes every scene take the staged path with
+// tiles of n records; a testing aid for exercising that path on small scenes.
+uint32_t forced_tile()
+{
+  const char * v = std::getenv("RT_HIP_FORCE_TILE");
+  if (v == nullptr)
+    return 0u;
+  uint32_t const n = (uint32_t)std::strtoul(v, nullptr, 10) / RT_PAD * RT_PAD;
+  return std::min(std::max(n, RT_PAD), kTileSpheres);
+}
+
+bool is_tiled(uint32_t n_padded) { return n_padded > kResidentSpheres || forced_tile() != 0u; }
+uint32_t tile_size() { return forced_tile() ? forced_tile() : kTileSpheres; }
 
 // Path stacks + either the resident scene (filter, camera table and exact records) or one staging tile.
 size_t lds_bytes(uint32_t n_padded)
@@ -379,7 +398,7 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
 // kernel.  The camera table lives in the scene, so one scene carries one trace at a time.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
                  float * d_partial, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
-                 hipEvent_t ev_start, hipEvent_t ev_stop)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, const uint32_t * d_cancel = nullptr)
 {
   TraceArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -392,12 +411,14 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.lights = scene->d_lights;
   a.n_spheres = scene->n_spheres;
   a.n_padded = scene->n_padded;
+  a.tile_size = tile_size();
   a.n_materials = scene->n_materials;
   a.n_lights = scene->n_lights;
   a.partial = d_partial;
   a.n_items = p->width * p->height * p->samples_in_row;
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
+  a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
 
   RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
   if (scene->n_padded > 0)
@@ -471,6 +492,7 @@ void free_job(rt_hip_job * job)
   if (job->d_planes) (void)hipFree(job->d_planes);
   if (job->d_rgb) (void)hipFree(job->d_rgb);
   if (job->d_stats) (void)hipFree(job->d_stats);
+  if (job->h_cancel) (void)hipHostFree(job->h_cancel);
   if (job->start) (void)hipEventDestroy(job->start);
   if (job->stop) (void)hipEventDestroy(job->stop);
   delete job;
@@ -510,6 +532,11 @@ int rt_hip_init(int device)
   std::snprintf(g_lib.name, sizeof(g_lib.name), "%s (%s)", prop.name, prop.gcnArchName);
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.copy_stream, hipStreamNonBlocking));
+  if (g_lib.never_cancel == nullptr)
+  {
+    RT_CHECK(hipMalloc((void **)&g_lib.never_cancel, 64));
+    RT_CHECK(hipMemset(g_lib.never_cancel, 0, 64));
+  }
   g_lib.ready = true;
   return RT_HIP_OK;
 }
@@ -639,6 +666,13 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
   if (e == hipSuccess) e = hipEventCreate(&job->start);
   if (e == hipSuccess) e = hipEventCreate(&job->stop);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&job->h_cancel, 64, hipHostMallocMapped);
+  uint32_t * d_cancel = nullptr;
+  if (e == hipSuccess)
+  {
+    *job->h_cancel = 0u;
+    e = hipHostGetDevicePointer((void **)&d_cancel, job->h_cancel, 0);
+  }
   // Unfinished columns read as black in snapshots.
   if (e == hipSuccess) e = hipMemsetAsync(job->d_partial, 0, partial_bytes(params), g_lib.stream);
   if (e != hipSuccess)
@@ -647,7 +681,7 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   }
   rc = launch_trace(scene, camera, params, job->d_partial, job->d_stats, true, g_lib.stream, job->start,
-                    job->stop);
+                    job->stop, d_cancel);
   if (rc != RT_HIP_OK)
   {
     (void)hipStreamSynchronize(g_lib.stream);
@@ -699,9 +733,9 @@ int rt_hip_job_cancel(rt_hip_job * job)
   if (job == nullptr)
     return fail(RT_HIP_ERR_INVALID, "null job");
   job->cancelled = true;
-  // Push the work queue past the end of the frame: lanes finish the column they hold and stop.
-  RT_CHECK(hipMemsetAsync(job->d_stats + kStatsWords, 0x7f, sizeof(uint32_t), g_lib.copy_stream));
-  RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
+  // The kernel reads this pinned word whenever a wave refills its pool of work items: lanes finish the
+  // columns they hold (at most one batch per wave) and stop.  No GPU command is needed to deliver it.
+  __atomic_store_n(job->h_cancel, 1u, __ATOMIC_RELEASE);
   return RT_HIP_OK;
 }
 

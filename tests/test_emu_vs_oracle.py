@@ -1,0 +1,114 @@
+"""The trace kernel's per-lane state machine, compiled for the host (tests/emu), against the oracle.
+
+This checks on the CPU what the GPU tests check on the device: the kernel's control flow (stage P / stage S,
+filter + exact resolution, multi-light passes, tiled scenes, slices) reproduces the reference's algorithm.
+"""
+import numpy as np
+import pytest
+
+import emu_ffi
+
+
+def rel_err(ref, out):
+    return np.abs(ref - out) / np.maximum(np.abs(ref), 1e-3)
+
+
+@pytest.mark.parametrize("demo,spheres", [(1, 0), (2, 0), (3, 300)])
+@pytest.mark.parametrize("depth", [1, 0])
+def test_deterministic_frames_match(oracle, ffi, scenes, demo, spheres, depth):
+    scene = scenes(demo, 1, spheres)
+    p = ffi.params(64, 48, 2, flags=ffi.FLAG_DETERMINISTIC, max_depth=depth)
+    ref, rs = oracle.render(scene, p, 4)
+    out, es = emu_ffi.render(scene, p)
+    assert rel_err(ref, out).max() < 1e-6  # column sums are added in a different association: ~1e-7
+    for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces"):
+        assert es[key] == getattr(rs, key), key
+
+
+def test_filter_is_conservative_on_the_demo_scenes(oracle, ffi, scenes):
+    """Same hit counts as the brute-force oracle: the filter never drops a ray the exact test accepts."""
+    for demo in (1, 2):
+        scene = scenes(demo)
+        p = ffi.params(96, 72, 2, flags=ffi.FLAG_DETERMINISTIC)
+        _, rs = oracle.render(scene, p, 8)
+        _, es = emu_ffi.render(scene, p)
+        assert es["hit_queries"] == rs.hit_queries and es["ray_queries"] == rs.ray_queries
+        assert es["exact_tests"] < 0.02 * es["sphere_tests"]  # and lets few candidates through
+
+
+@pytest.mark.parametrize("demo", [1, 2])
+def test_stochastic_frames_share_the_random_streams(oracle, ffi, scenes, demo):
+    scene = scenes(demo)
+    p = ffi.params(64, 48, 2, seed=7)
+    ref, rs = oracle.render(scene, p, 4)
+    out, es = emu_ffi.render(scene, p)
+    err = rel_err(ref, out).max(axis=2)
+    assert (err > 1e-3).mean() < 2e-3  # a handful of pixels where rounding flips a branch
+    assert np.abs(ref - out).mean() < 1e-5
+    assert abs(es["ray_queries"] - rs.ray_queries) <= 1e-3 * rs.ray_queries
+
+
+@pytest.mark.parametrize("tile", [8, 64, 128])
+def test_tiled_scene_equals_resident_scene(ffi, scenes, tile):
+    scene = scenes(3, 1, 300)
+    p = ffi.params(40, 30, 2, seed=3)
+    a, sa = emu_ffi.render(scene, p, 0)
+    b, sb = emu_ffi.render(scene, p, tile)
+    np.testing.assert_array_equal(a, b)
+    assert sa == sb
+
+
+@pytest.mark.parametrize("slices", [2, 5])
+def test_slices(oracle, ffi, scenes, slices):
+    scene = scenes(1)
+    total = 0.0
+    for i in range(slices):
+        p = ffi.params(40, 30, 2, seed=9, slice_index=i, slice_count=slices)
+        ref, _ = oracle.render(scene, p, 4)
+        out, _ = emu_ffi.render(scene, p)
+        assert np.abs(ref - out).mean() < 1e-5
+        total = total + out.astype(np.float64)
+    full, _ = emu_ffi.render(scene, ffi.params(40, 30, 2, seed=9))
+    np.testing.assert_allclose(total, full, rtol=2e-6, atol=1e-7)
+
+
+def small_scene(ffi, lights):
+    mats = [(0, (0.7, 0.6, 0.5), 0.7, 0.0), (1, (0.9, 0.8, 0.3), 0.1, 0.15), (2, (0.3, 0.9, 0.8), 0.0, 0.85)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0), (-1.2, -0.5, 2.0, 0.5, 1), (0.0, -0.4, 1.0, 0.6, 2), (1.3, -0.6, 2.5, 0.4, 0)]
+    return ffi.Scene.build(spheres, mats, lights, dict(position=(0.0, 0.5, -3.0), direction=(0.0, -0.2, 1.0),
+                                                       background=(0.8, 0.85, 0.9)))
+
+
+@pytest.mark.parametrize("lights", [
+    [],
+    [((-0.3, -0.9, 0.3), (1.0, 1.0, 1.0)), ((0.5, -0.7, -0.5), (0.4, 0.3, 0.6))],
+    [((0.0, -1.0, 0.0), (1.0, 0.5, 0.25)), ((0.6, -0.6, 0.5), (0.2, 0.9, 0.2)), ((-0.6, -0.6, -0.5), (0.5, 0.5, 0.9))],
+], ids=["no_light", "two_lights", "three_lights"])
+def test_light_counts(oracle, ffi, lights):
+    def normalise(d):
+        d = np.asarray(d, dtype=np.float64)
+        return tuple(d / np.linalg.norm(d))
+
+    scene = small_scene(ffi, [(normalise(d), c) for d, c in lights])
+    for flags in (ffi.FLAG_DETERMINISTIC, 0):
+        p = ffi.params(48, 36, 2, flags=flags, seed=4)
+        ref, rs = oracle.render(scene, p, 4)
+        out, es = emu_ffi.render(scene, p)
+        if flags:
+            assert rel_err(ref, out).max() < 1e-6
+            assert es["ray_queries"] == rs.ray_queries
+        else:
+            assert np.abs(ref - out).mean() < 2e-5
+
+
+def test_absorbing_metal_and_energy_break(oracle, ffi):
+    """A very rough metal (emissivity 0.9 * (1 - 0.95)) drives the reverse loop into its early break."""
+    mats = [(1, (0.9, 0.9, 0.9), 0.95, 0.1), (0, (0.5, 0.5, 0.5), 0.7, 0.0)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0), (0.0, 0.0, 2.0, 1.0, 0), (2.1, 0.0, 2.0, 1.0, 0), (-2.1, 0.0, 2.0, 1.0, 1)]
+    scene = ffi.Scene.build(spheres, mats, [((0.0, -1.0, 0.0), (1.0, 1.0, 1.0))],
+                            dict(position=(0.0, 0.5, -4.0), direction=(0.0, -0.1, 1.0)))
+    p = ffi.params(48, 36, 3, seed=8)
+    ref, rs = oracle.render(scene, p, 4)
+    out, es = emu_ffi.render(scene, p)
+    assert np.abs(ref - out).mean() < 2e-5
+    assert abs(es["shaded_bounces"] - rs.shaded_bounces) <= 2e-3 * rs.shaded_bounces

@@ -1,0 +1,109 @@
+"""The drop-in boundary on a real GPU: the asynchronous job API, the Frame plug-in on top of it, the CLI."""
+import ctypes as C
+import json
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_device_is_an_mi355x(hip):
+    info = hip.device_info()
+    assert "gfx950" in info["name"]
+    assert info["compute_units"] == 256
+
+
+def test_job_runs_asynchronously_and_snapshots_progress(hip, ffi, scenes):
+    scene = scenes(2)
+    p = ffi.params(1920, 1080, 16, seed=3)
+    t0 = time.perf_counter()
+    job = hip.start(scene, p)
+    launch = time.perf_counter() - t0
+    assert hip.poll(job) == ffi.RT_HIP_ERR_NOT_READY
+    snap = hip.snapshot(job, p)  # must not wait for the trace
+    still_running = hip.poll(job) == ffi.RT_HIP_ERR_NOT_READY
+    final, st = hip.finish(job, p)
+    assert launch < 0.02  # returned long before the frame finished
+    # a snapshot holds finished columns only: every pixel is at most its final value, unfinished ones darker
+    assert (snap <= final * (1 + 1e-5) + 1e-6).all()
+    assert still_running and (snap.sum(axis=2) < final.sum(axis=2) * 0.999).any()
+    assert st.samples == 1920 * 1080 * 256 and st.kernel_ms > 0
+
+
+def test_cancel_stops_the_frame_early(hip, ffi, scenes):
+    scene = scenes(1)
+    p = ffi.params(3840, 2160, 8, seed=3)
+    job = hip.start(scene, p)
+    hip.cancel(job)
+    _, st = hip.finish(job, p, allow_cancelled=True)
+    assert st.samples < 3840 * 2160 * 64
+
+
+def test_invalid_arguments_are_reported(hip, ffi, scenes):
+    lib = hip.lib
+    scene = scenes(1)
+    handle = hip.upload(scene)
+    job = C.c_void_p()
+    bad = ffi.params(0, 10, 2)
+    assert lib.rt_hip_trace_async(handle, C.byref(scene.camera), C.byref(bad), C.byref(job)) == 1
+    assert b"positive" in lib.rt_hip_last_error()
+    bad = ffi.params(8, 8, 2, slice_index=3, slice_count=2)
+    assert lib.rt_hip_trace_async(handle, C.byref(scene.camera), C.byref(bad), C.byref(job)) == 1
+    mats = (ffi.Material * 1)()
+    mats[0].type = 7
+    out = C.c_void_p()
+    assert lib.rt_hip_scene_create(None, None, 0, mats, 1, None, 0, C.byref(out)) == 1
+    assert b"material type" in lib.rt_hip_last_error()
+
+
+def test_device_entry_points_match_the_job_api(hip, ffi, scenes):
+    import torch
+
+    scene = scenes(1)
+    p = ffi.params(200, 120, 3, seed=4)
+    ref, rs = hip.render(scene, p)
+    planes = torch.empty(3 * 200 * 120, dtype=torch.float32, device="cuda")
+    rgb = torch.empty(200 * 120 * 3, dtype=torch.float32, device="cuda")
+    stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    hip.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
+    hip.resolve_device(planes.data_ptr(), rgb.data_ptr(), p, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rgb.cpu().numpy().reshape(120, 200, 3), ref)
+    assert int(stats[0]) == rs.samples and int(stats[1]) == rs.ray_queries
+
+
+def test_frame_plugin_renders_the_demo(hip, ffi, scenes):
+    """DemoFrameHIP driven as the reference's App drives a Frame equals the C ABI called directly."""
+    p = ffi.params(160, 120, 2, seed=6)
+    direct, _ = hip.render(scenes(1), p)
+    via_frame, st = ffi.render_demo(1, p, scene_seed=1)
+    np.testing.assert_array_equal(via_frame, direct)
+    assert st.samples == 160 * 120 * 4
+
+
+def test_cli_writes_the_frame(hip, ffi, scenes, tmp_path):
+    out = tmp_path / "frame.pfm"
+    cmd = [os.path.join(ROOT, "rt_amd", "bin", "rt_cli"), "-w", "96", "-h", "64", "-s", "2", "-d", "2", "--seed", "5",
+           "--out", str(out), "--progress"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["samples"] == 96 * 64 * 4 and info["backend"] == "hip"
+    raw = out.read_bytes()
+    header, data = raw.split(b"-1.0\n", 1)
+    assert header.split() == [b"PF", b"96", b"64"]
+    img = np.frombuffer(data, dtype="<f4").reshape(64, 96, 3)[::-1]  # PFM rows run bottom-up
+    ref, _ = hip.render(scenes(2), ffi.params(96, 64, 2, seed=5))
+    np.testing.assert_array_equal(img, ref)
+    # 8-bit output goes through the viewer's conversion
+    ppm = tmp_path / "frame.ppm"
+    subprocess.run(cmd[:-3] + ["--out", str(ppm)], check=True, capture_output=True, timeout=120)
+    body = ppm.read_bytes().split(b"255\n", 1)[1]
+    np.testing.assert_array_equal(np.frombuffer(body, dtype=np.uint8).reshape(64, 96, 3), ffi.update_texture(ref)[..., :3])

@@ -1,0 +1,164 @@
+"""Parity of the HIP backend with the oracle, through the C ABI, on a real MI355X.
+
+Tolerances (from the build's north star):
+  * deterministic mode (no stochastic scattering): every pixel within 1e-4 relative (floor 1e-3 absolute
+    radiance in the denominator) of the CPU path;
+  * stochastic mode, same Philox streams on both sides: mean absolute error below 1e-4 and at most 0.5 % of
+    the pixels off by more than 1e-3 relative (pixels where a last-bit difference flips a branch);
+  * converged renders (144 samples per pixel) with different seeds: PSNR above 35 dB, mean absolute error
+    within 1.25x of what two CPU renders with different seeds differ by, mean radiance within 1e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_err(ref, out):
+    return np.abs(ref - out) / np.maximum(np.abs(ref), 1e-3)
+
+
+def psnr(a, b):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 10.0 * np.log10(1.0 / max(mse, 1e-20))
+
+
+@pytest.mark.parametrize("demo,spheres", [(1, 0), (2, 0), (3, 300), (3, 3000)], ids=["pretty", "glass", "field300", "field3000"])
+@pytest.mark.parametrize("depth", [1, 0], ids=["D1", "D2"])
+def test_deterministic_mode_per_pixel(hip, oracle, ffi, scenes, demo, spheres, depth):
+    scene = scenes(demo, 1, spheres)
+    w, h = (128, 96) if spheres < 1000 else (64, 48)
+    p = ffi.params(w, h, 2, flags=ffi.FLAG_DETERMINISTIC, max_depth=depth)
+    ref, rs = oracle.render(scene, p)
+    out, st = hip.render(scene, p)
+    err = rel_err(ref, out)
+    assert err.max() < 1e-4, "max relative error %.3g at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert st.samples == rs.samples and st.ray_queries == rs.ray_queries
+    assert st.hit_queries == rs.hit_queries and st.shaded_bounces == rs.shaded_bounces
+
+
+@pytest.mark.parametrize("name,demo,spheres", [("pretty", 1, 0), ("glass", 2, 0), ("synthetic300", 3, 300)])
+@pytest.mark.parametrize("mode,depth", [("d1", 1), ("d2", 0)])
+def test_against_committed_golden_frames(hip, ffi, scenes, name, demo, spheres, mode, depth):
+    golden = np.load(os.path.join(GOLDEN, "frame_%s_%s.npy" % (name, mode)))
+    p = ffi.params(64, 48, 2, flags=ffi.FLAG_DETERMINISTIC, seed=1, max_depth=depth)
+    out, _ = hip.render(scenes(demo, 1, spheres), p)
+    assert rel_err(golden, out).max() < 1e-4
+
+
+@pytest.mark.parametrize("w,h,s", [(1, 1, 1), (3, 5, 1), (37, 23, 3), (130, 2, 4), (64, 48, 5)])
+def test_ragged_frame_shapes(hip, oracle, ffi, scenes, w, h, s):
+    scene = scenes(1)
+    p = ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC)
+    ref, _ = oracle.render(scene, p)
+    out, st = hip.render(scene, p)
+    assert st.samples == w * h * s * s
+    assert rel_err(ref, out).max() < 1e-4
+
+
+@pytest.mark.parametrize("demo", [1, 2], ids=["pretty", "glass"])
+def test_stochastic_mode_shares_the_random_streams(hip, oracle, ffi, scenes, demo):
+    scene = scenes(demo)
+    p = ffi.params(160, 120, 3, seed=7)
+    ref, rs = oracle.render(scene, p)
+    out, st = hip.render(scene, p)
+    assert np.abs(ref - out).mean() < 1e-4
+    assert (rel_err(ref, out).max(axis=2) > 1e-3).mean() < 5e-3
+    assert st.samples == rs.samples
+    assert abs(int(st.ray_queries) - int(rs.ray_queries)) < 1e-3 * rs.ray_queries
+
+
+@pytest.mark.parametrize("demo", [1, 2], ids=["pretty", "glass"])
+def test_converged_render(hip, oracle, ffi, scenes, demo):
+    """Different seeds on the two sides: only the converged image can agree."""
+    scene = scenes(demo)
+    ref, _ = oracle.render(scene, ffi.params(160, 120, 12, seed=11))
+    ref2, _ = oracle.render(scene, ffi.params(160, 120, 12, seed=77))
+    out, _ = hip.render(scene, ffi.params(160, 120, 12, seed=1234))
+    assert psnr(ref, out) > 35.0
+    # the Monte-Carlo noise floor at 144 samples per pixel is what two CPU renders differ by
+    noise = float(np.abs(ref - ref2).mean())
+    assert np.abs(ref - out).mean() < 1.25 * noise < 1e-2
+    assert abs(float(ref.mean()) - float(out.mean())) < 1e-3
+
+
+def test_empty_scene_and_no_lights(hip, oracle, ffi):
+    empty = ffi.Scene.build([], [], [], dict(position=(0, 0, 0), direction=(0, 0, 1), background=(0.2, 0.5, 0.9)))
+    out, st = hip.render(empty, ffi.params(33, 17, 2))
+    np.testing.assert_allclose(out, np.broadcast_to(np.float32([0.2, 0.5, 0.9]), out.shape), rtol=1e-6)
+    assert st.hit_queries == 0 and st.ray_queries == st.samples
+    mats = [(0, (0.7, 0.6, 0.5), 0.7, 0.0), (2, (0.3, 0.9, 0.8), 0.0, 0.85)]
+    dark = ffi.Scene.build([(0.0, -1001.0, 0.0, 1000.0, 0), (0.0, -0.4, 1.0, 0.6, 1)], mats, [],
+                           dict(position=(0.0, 0.5, -3.0), direction=(0.0, -0.2, 1.0)))
+    p = ffi.params(64, 48, 2, flags=ffi.FLAG_DETERMINISTIC)
+    ref, rs = oracle.render(dark, p)
+    out, st = hip.render(dark, p)
+    assert rel_err(ref, out).max() < 1e-4 and st.ray_queries == rs.ray_queries
+
+
+def test_several_lights(hip, oracle, ffi):
+    def unit(d):
+        d = np.asarray(d, dtype=np.float64)
+        return tuple(d / np.linalg.norm(d))
+
+    mats = [(0, (0.7, 0.6, 0.5), 0.7, 0.0), (1, (0.9, 0.8, 0.3), 0.1, 0.15), (2, (0.3, 0.9, 0.8), 0.0, 0.85)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0), (-1.2, -0.5, 2.0, 0.5, 1), (0.0, -0.4, 1.0, 0.6, 2), (1.3, -0.6, 2.5, 0.4, 0)]
+    lights = [(unit((0.0, -1.0, 0.0)), (1.0, 0.5, 0.25)), (unit((0.6, -0.6, 0.5)), (0.2, 0.9, 0.2)),
+              (unit((-0.6, -0.6, -0.5)), (0.5, 0.5, 0.9))]
+    scene = ffi.Scene.build(spheres, mats, lights, dict(position=(0.0, 0.5, -3.0), direction=(0.0, -0.2, 1.0)))
+    p = ffi.params(96, 72, 2, flags=ffi.FLAG_DETERMINISTIC)
+    ref, rs = oracle.render(scene, p)
+    out, st = hip.render(scene, p)
+    assert rel_err(ref, out).max() < 1e-4 and st.ray_queries == rs.ray_queries
+    p = ffi.params(96, 72, 3, seed=2)
+    ref, _ = oracle.render(scene, p)
+    out, _ = hip.render(scene, p)
+    assert np.abs(ref - out).mean() < 1e-4
+
+
+def test_energy_break_and_absorbing_metal(hip, oracle, ffi):
+    mats = [(1, (0.9, 0.9, 0.9), 0.95, 0.1), (0, (0.5, 0.5, 0.5), 0.7, 0.0)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0), (0.0, 0.0, 2.0, 1.0, 0), (2.1, 0.0, 2.0, 1.0, 0), (-2.1, 0.0, 2.0, 1.0, 1)]
+    scene = ffi.Scene.build(spheres, mats, [((0.0, -1.0, 0.0), (1.0, 1.0, 1.0))],
+                            dict(position=(0.0, 0.5, -4.0), direction=(0.0, -0.1, 1.0)))
+    p = ffi.params(96, 72, 3, seed=8)
+    ref, _ = oracle.render(scene, p)
+    out, _ = hip.render(scene, p)
+    assert np.abs(ref - out).mean() < 1e-4
+
+
+@pytest.mark.parametrize("slices", [2, 3, 8])
+def test_slices_add_up(hip, oracle, ffi, scenes, slices):
+    scene = scenes(1)
+    full, fs = hip.render(scene, ffi.params(96, 72, 2, seed=9))
+    total = np.zeros(full.shape, dtype=np.float64)
+    samples = 0
+    for i in range(slices):
+        p = ffi.params(96, 72, 2, seed=9, slice_index=i, slice_count=slices)
+        part, st = hip.render(scene, p)
+        ref, _ = oracle.render(scene, p)
+        assert np.abs(ref - part).mean() < 1e-4
+        total += part
+        samples += st.samples
+    assert samples == fs.samples
+    np.testing.assert_allclose(total, full, rtol=2e-6, atol=1e-7)
+
+
+def test_full_size_frame_properties(hip, ffi, scenes):
+    """The benchmark's frame (1920x1080, 16x16): properties that need no CPU render."""
+    scene = scenes(1)
+    p = ffi.params(1920, 1080, 16, seed=1)
+    a, sa = hip.render(scene, p)
+    b, sb = hip.render(scene, p)
+    np.testing.assert_array_equal(a, b)  # no atomics on pixels: bitwise reproducible
+    assert sa.samples == 1920 * 1080 * 256
+    assert sa.samples + 5 * sa.shaded_bounces <= sa.ray_queries <= sa.samples + 6 * sa.shaded_bounces
+    assert sa.sphere_tests >= sa.ray_queries * scene.sphere_count
+    np.testing.assert_allclose(a[0, :, :], 0.9, rtol=1e-6)  # the top row sees only sky
+    assert np.isfinite(a).all() and a.min() >= 0.0
+    # the low-resolution oracle render of the same view has the same mean radiance
+    assert abs(float(a.mean()) - 0.746) < 0.01

@@ -1,0 +1,73 @@
+"""The C++ host: object model, demo scenes and their flattening (librt_host, include/rt_host.h)."""
+import numpy as np
+import pytest
+
+
+def test_demo_scenes_have_the_reference_shape(scenes):
+    for demo in (1, 2):
+        s = scenes(demo)
+        assert s.sphere_count == 41 and s.light_count == 1  # 40 + ground (demos/pretty_spheres.hpp:58-83)
+        np.testing.assert_allclose(s.centers_radii[40], [0.0, -1001.0, 0.0, 1000.0])
+        r = s.centers_radii[:40, 3]
+        assert r.min() >= 0.25 and r.max() <= 0.5
+        np.testing.assert_allclose(s.centers_radii[:40, 1], r - 1.0, rtol=1e-6)  # resting on y = -1
+        xz = {(float(x), float(z)) for x, _, z, _ in s.centers_radii[:40]}
+        assert len(xz) == 40 and all(x == round(x) and -5 <= x <= 5 and z == round(z) and -5 <= z <= 5 for x, z in xz)
+        d = np.array(list(s.lights[0].direction))
+        np.testing.assert_allclose(d, np.array([-0.4, -1.0, 0.6]) / np.linalg.norm([-0.4, -1.0, 0.6]), rtol=1e-6)
+        assert np.linalg.norm(list(s.camera.direction)) == pytest.approx(1.0, rel=1e-6)
+        assert s.camera.fov == pytest.approx(2.0 * np.pi / 3.0, rel=1e-6)
+        assert (s.camera.znear, s.camera.zfar) == (pytest.approx(0.001), 1000.0)
+
+
+def test_material_getters_are_flattened_as_the_reference_does(scenes):
+    pretty = scenes(1)
+    mats = [pretty.materials[i] for i in range(pretty.material_count)]
+    kinds = [mats[i].type for i in pretty.material_index]
+    assert kinds[:15] == [0] * 15 and kinds[15:40] == [1] * 25 and kinds[40] == 0  # 15 matte, 25 metal, ground
+    for m in mats:
+        if m.type == 0:  # Matte keeps Material's defaults (ray_tracing/material.hpp:25-26)
+            assert m.roughness == pytest.approx(0.7) and m.refraction == 0.0
+        else:
+            assert 0.0 <= m.roughness <= 0.2 and 0.0 <= m.refraction <= 0.2
+    glass = scenes(2)
+    for i in range(40):
+        m = glass.materials[glass.material_index[i]]
+        assert m.type == 2 and m.roughness == 0.0 and 0.8 <= m.refraction <= 0.9
+    ground = glass.materials[glass.material_index[40]]
+    assert ground.type == 0 and list(ground.albedo) == pytest.approx([0.4, 0.4, 0.4])
+
+
+def test_scenes_are_reproducible_and_seeded(ffi):
+    a, b, c = ffi.Scene.demo(1, 1), ffi.Scene.demo(1, 1), ffi.Scene.demo(1, 2)
+    np.testing.assert_array_equal(a.centers_radii, b.centers_radii)
+    assert not np.array_equal(a.centers_radii, c.centers_radii)
+
+
+def test_synthetic_field(ffi):
+    s = ffi.Scene.demo(3, 1, 10000)
+    assert s.sphere_count == 10001 and s.light_count == 1
+    c = s.centers_radii[:10000]
+    assert c[:, 3].min() >= 0.25 and c[:, 3].max() <= 0.5
+    # one sphere per unit cell, inside its cell: no two can overlap
+    cells = np.floor(c[:, [0, 2]] + 50.0).astype(int)
+    assert len({(int(x), int(z)) for x, z in cells}) == 10000
+    kinds = np.array([s.materials[i].type for i in s.material_index[:10000]])
+    assert set(kinds) == {0, 1, 2} and min(np.bincount(kinds)) > 3000
+
+
+def test_update_texture_matches_the_viewer(ffi):
+    rgb = np.array([[-0.5, 0.0, 0.25], [0.5, 0.999, 1.0], [1.5, 0.0039, 0.9961]], dtype=np.float32)
+    out = ffi.update_texture(rgb)
+    expect = (255 * np.clip(rgb, 0.0, 1.0)).astype(np.uint8)  # truncation, app.cpp:132-134
+    np.testing.assert_array_equal(out[:, :3], expect)
+    assert (out[:, 3] == 255).all()
+
+
+def test_sharding_rule():
+    from rt_amd import sharding
+
+    for s_row, count in ((2, 8), (16, 8), (3, 2), (10, 4)):
+        owners = [sharding.owner_of(p, sx, s_row, count) for p in range(64) for sx in range(s_row)]
+        per = np.bincount(owners, minlength=count)
+        assert per.max() - per.min() <= 1  # balanced whatever divides what
