@@ -180,7 +180,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, max(w // 4, 16), max(h // 4, 16), min(s, 8))
+            out["cpu_baseline"] = cpu_baseline(scene, max(w // 2, 16), max(h // 2, 16), s)
         print(json.dumps(out), flush=True)
 
     renderer.close()

@@ -80,7 +80,7 @@ typedef struct
   uint32_t height;
   uint32_t samples_in_row; /* S: S*S samples per pixel, regular grid (ray_tracing/frame.cpp:56-66) */
   uint32_t flags;          /* RT_HIP_FLAG_* */
-  uint32_t seed;           /* Philox4x32-10 key word: key = (pixel, sample ^ seed), counter = (bounce, block) */
+  uint32_t seed;           /* Philox4x32-10 key word: key = (pixel, seed), counter = (bounce, block, sample, 0) */
   uint32_t max_depth;      /* 0 -> 10 (demos/demo_frame_cpu.cpp:10); 1 = primary hit + direct light only */
   uint32_t slice_index;    /* see "Conventions" */
   uint32_t slice_count;    /* 0 or 1 -> the whole sample space */

@@ -107,8 +107,8 @@ void orc_ball(float radius, float u1, float u2, float u3, float out[3])
 static void philox_block(const orc_params * params, uint32_t pixel, uint32_t sample, uint32_t bounce,
                          uint32_t block, uint32_t w[4])
 {
-  uint32_t const ctr[4] = {bounce, block, 0u, 0u};
-  uint32_t const key[2] = {pixel, sample ^ params->seed};
+  uint32_t const ctr[4] = {bounce, block, sample, 0u};
+  uint32_t const key[2] = {pixel, params->seed};
   orc_philox4x32_10(ctr, key, w);
 }
 

@@ -12,7 +12,7 @@
  * glm's published GLSL-equivalent definitions for dot/normalize/cross/reflect/refract/mix/clamp.
  * The only intentional departure is the random source: the reference draws glm::ballRand /
  * glm::linearRand from the C library generator; here every draw comes from Philox4x32-10 keyed on
- * (pixel, sample ^ seed) with counter (bounce, block), so the CPU and GPU see identical streams.
+ * (pixel, seed) with counter (bounce, block, sample), so the CPU and GPU see identical streams.
  *
  * All arithmetic is IEEE binary32 with float math functions (sqrtf, powf, expf, tanf), no FMA
  * contraction (build with -ffp-contract=off).

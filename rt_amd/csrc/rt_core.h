@@ -185,7 +185,7 @@ RT_FN float pow5(float x)
   return x2 * x2 * x;
 }
 
-// ---- Philox4x32-10, key = (pixel, sample ^ seed), counter = (bounce, block, 0, 0) ----
+// ---- Philox4x32-10, key = (pixel, seed), counter = (bounce, block, sample, 0) ----
 RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -736,7 +736,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       float xi = 0.5f;
       if (!deterministic)
       {
-        u4 const rw = philox4x32_10(L.depth, 0u, 0u, 0u, L.pixel, L.sample ^ A.seed);
+        u4 const rw = philox4x32_10(L.depth, 0u, L.sample, 0u, L.pixel, A.seed);
         ball = ball3(1.0f, uniform24(rw.x), uniform24(rw.y), uniform24(rw.z));
         xi = uniform24(rw.w);
       }
@@ -783,8 +783,8 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         if (!deterministic)
         {
           // 15 uniforms of 16 bits from two Philox blocks: half-words h[0..15], ball j takes h[3j..3j+2].
-          u4 const p0 = philox4x32_10(L.depth, 1u + 2u * L.li, 0u, 0u, L.pixel, L.sample ^ A.seed);
-          u4 const p1 = philox4x32_10(L.depth, 2u + 2u * L.li, 0u, 0u, L.pixel, L.sample ^ A.seed);
+          u4 const p0 = philox4x32_10(L.depth, 1u + 2u * L.li, L.sample, 0u, L.pixel, A.seed);
+          u4 const p1 = philox4x32_10(L.depth, 2u + 2u * L.li, L.sample, 0u, L.pixel, A.seed);
           uint32_t const wd[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
           for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
