@@ -27,6 +27,15 @@ $(BIN)/rt_cli: rt_amd/host/cli/main.cpp $(HOST_HDRS) $(LIB)/librt_host.so
 	$(CXX) $(CXXFLAGS) rt_amd/host/cli/main.cpp -L$(LIB) -lrt_host -lrt_hip \
 	    -Wl,-rpath,'$$ORIGIN/../lib' -pthread -o $@
 
+# Profiling build of the kernels with region probes (tools/region_profile.py); never shipped.
+prof: rt_amd/lib_prof/librt_hip.so rt_amd/lib_prof/librt_host.so
+rt_amd/lib_prof/librt_host.so: $(LIB)/librt_host.so
+	@mkdir -p rt_amd/lib_prof
+	cp $(LIB)/librt_host.so $@
+rt_amd/lib_prof/librt_hip.so: rt_amd/csrc/rt_hip.hip $(CORE_HDRS)
+	@mkdir -p rt_amd/lib_prof
+	$(HIPCC) $(HIPFLAGS) -DRT_PROFILE_REGIONS -shared rt_amd/csrc/rt_hip.hip -o $@
+
 checkers: oracle/librt_oracle.so tests/emu/libcore_emu.so
 
 oracle/librt_oracle.so: oracle/rt_oracle.c oracle/rt_oracle.h
@@ -39,4 +48,4 @@ clean:
 	rm -f $(LIB)/*.so $(BIN)/rt_cli tests/emu/libcore_emu.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all checkers clean
+.PHONY: all checkers prof clean

@@ -100,49 +100,8 @@ RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 RT_FN int hw_clz(uint32_t x) { return __clz((int)x); }
 RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
-// mask[r] = 2 * mask[r] + (x[r] >= bound) for six rays: six compares into six SGPR pairs, then six
-// add-with-carry that shift the results in.  Written as one block because gfx950 wants two wait states
-// between a VALU write of a lane mask and a VALU read of it, and the compiler pads nothing inside an asm
-// statement: here every add-with-carry reads a mask written six instructions earlier.  For the same reason
-// `bound` must not come straight out of a transcendental instruction (one wait state): callers pass it
-// through an ordinary VALU instruction first.
-RT_FN void push_ge6(uint32_t (&mask)[RT_RAYS], const float (&x)[RT_RAYS], float bound)
-{
-  unsigned long long c0, c1, c2, c3, c4, c5;
-  asm("v_cmp_ge_f32_e64 %[c0], %[x0], %[b]\n\t"
-      "v_cmp_ge_f32_e64 %[c1], %[x1], %[b]\n\t"
-      "v_cmp_ge_f32_e64 %[c2], %[x2], %[b]\n\t"
-      "v_cmp_ge_f32_e64 %[c3], %[x3], %[b]\n\t"
-      "v_cmp_ge_f32_e64 %[c4], %[x4], %[b]\n\t"
-      "v_cmp_ge_f32_e64 %[c5], %[x5], %[b]\n\t"
-      "v_addc_co_u32_e64 %[m0], %[c0], %[m0], %[m0], %[c0]\n\t"
-      "v_addc_co_u32_e64 %[m1], %[c1], %[m1], %[m1], %[c1]\n\t"
-      "v_addc_co_u32_e64 %[m2], %[c2], %[m2], %[m2], %[c2]\n\t"
-      "v_addc_co_u32_e64 %[m3], %[c3], %[m3], %[m3], %[c3]\n\t"
-      "v_addc_co_u32_e64 %[m4], %[c4], %[m4], %[m4], %[c4]\n\t"
-      "v_addc_co_u32_e64 %[m5], %[c5], %[m5], %[m5], %[c5]"
-      : [m0] "+v"(mask[0]), [m1] "+v"(mask[1]), [m2] "+v"(mask[2]), [m3] "+v"(mask[3]), [m4] "+v"(mask[4]),
-        [m5] "+v"(mask[5]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4),
-        [c5] "=&s"(c5)
-      : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]),
-        [b] "v"(bound));
-}
-// The same for four table entries of one ray: mask = 16 * mask + the four results, first entry highest.
-RT_FN void push_ge4(uint32_t & mask, const float (&x)[4], const float (&bound)[4])
-{
-  unsigned long long c0, c1, c2, c3;
-  asm("v_cmp_ge_f32_e64 %[c0], %[x0], %[b0]\n\t"
-      "v_cmp_ge_f32_e64 %[c1], %[x1], %[b1]\n\t"
-      "v_cmp_ge_f32_e64 %[c2], %[x2], %[b2]\n\t"
-      "v_cmp_ge_f32_e64 %[c3], %[x3], %[b3]\n\t"
-      "v_addc_co_u32_e64 %[m], %[c0], %[m], %[m], %[c0]\n\t"
-      "v_addc_co_u32_e64 %[m], %[c1], %[m], %[m], %[c1]\n\t"
-      "v_addc_co_u32_e64 %[m], %[c2], %[m], %[m], %[c2]\n\t"
-      "v_addc_co_u32_e64 %[m], %[c3], %[m], %[m], %[c3]"
-      : [m] "+v"(mask), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
-      : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [b0] "v"(bound[0]), [b1] "v"(bound[1]),
-        [b2] "v"(bound[2]), [b3] "v"(bound[3]));
-}
+// mask = 2 * mask + (the sign bit of x): one v_alignbit_b32.
+RT_FN uint32_t push_sign(uint32_t mask, float x) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(x), 31u); }
 #else
 RT_FN float hw_sqrt(float x) { return sqrtf(x); }
 RT_FN float hw_rsq(float x) { return 1.0f / sqrtf(x); }
@@ -160,16 +119,7 @@ RT_FN uint32_t f2u(float f)
   return u;
 }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
-RT_FN void push_ge6(uint32_t (&mask)[RT_RAYS], const float (&x)[RT_RAYS], float bound)
-{
-  for (int r = 0; r < RT_RAYS; ++r)
-    mask[r] = mask[r] + mask[r] + (x[r] >= bound ? 1u : 0u);
-}
-RT_FN void push_ge4(uint32_t & mask, const float (&x)[4], const float (&bound)[4])
-{
-  for (int u = 0; u < 4; ++u)
-    mask = mask + mask + (x[u] >= bound[u] ? 1u : 0u);
-}
+RT_FN uint32_t push_sign(uint32_t mask, float x) { return (mask << 1) | (f2u(x) >> 31); }
 #endif
 
 // ---- exact helpers: the GLSL definitions glm follows, IEEE sqrt and division ----
@@ -249,11 +199,31 @@ struct TraceArgs
   unsigned long long * stats; // counters, see rt_hip.hip
 };
 
+#define RT_REGION_COUNT 12
 struct LaneCounters
 {
   uint32_t samples, queries, hits, shaded, filter_tests, exact_tests;
   uint32_t trips, rounds;  // loop trips and stage-P rounds this lane sat through, busy or not
+#if defined(RT_PROFILE_REGIONS)
+  // Profiling builds only: wave clock ticks spent in each region of the loop (see RT_REGION).
+  unsigned long long region[RT_REGION_COUNT];
+  unsigned long long last_tick;
+#endif
 };
+
+// RT_REGION(cnt, k) charges the time since the previous probe to region k.  Compiled in only with
+// -DRT_PROFILE_REGIONS (tools/region_profile.py); the shipped library carries no probes.
+#if defined(RT_PROFILE_REGIONS) && defined(__HIP_DEVICE_COMPILE__)
+#define RT_REGION(cnt, k)                                                   \
+  do                                                                        \
+  {                                                                         \
+    unsigned long long const now_ = __builtin_amdgcn_s_memtime();           \
+    (cnt).region[k] += now_ - (cnt).last_tick;                              \
+    (cnt).last_tick = now_;                                                 \
+  } while (0)
+#else
+#define RT_REGION(cnt, k) ((void)0)
+#endif
 
 // The filter.  With d = C - O and unit D, the ray can hit the sphere in front of O only if
 // dot(d, D) >= sqrt(c), c = |d|^2 - r^2.  The bound is taken from c - m (|d|^2 + r^2), m = RT_FILTER_MARGIN
@@ -435,24 +405,30 @@ RT_FN void push(f4 * stack, uint32_t stride, uint32_t depth, f3 l, float e)
   stack[depth * stride] = s;
 }
 
+// The filter keeps its outcome as the sign of dot(d, D) - bound, accumulated in one FMA chain that starts from
+// -bound, and shifts that sign bit into the lane's mask: a set bit means "rejected".  chunk_candidates turns
+// the `count` bits shifted in into the candidate mask (entry j of the chunk in bit count - 1 - j).
+RT_FN uint32_t chunk_candidates(uint32_t rejected, uint32_t count)
+{
+  uint32_t const valid = (count >= 32u) ? 0xFFFFFFFFu : ((1u << count) - 1u);
+  return ~rejected & valid;
+}
+
 // Filter of one ray against `count` (<= RT_CHUNK, a multiple of RT_PAD) camera-table entries
-// (centre - camera, bound): entry j of the chunk ends up in bit (count - 1 - j) of the mask.
+// (centre - camera, bound).
 RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
 {
   uint32_t mask = 0;
   for (uint32_t j = 0; j < count; j += RT_PAD)
   {
-    float x[RT_PAD], bound[RT_PAD];
 #pragma unroll
     for (uint32_t u = 0; u < RT_PAD; ++u)
     {
       f4 const e = tab[j + u];
-      x[u] = hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, e.x * dir.x));
-      bound[u] = e.w;
+      mask = push_sign(mask, hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, hw_fma(e.x, dir.x, -e.w))));
     }
-    push_ge4(mask, x, bound);
   }
-  return mask;
+  return chunk_candidates(mask, count);
 }
 
 // Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK, a multiple of RT_PAD) spheres.
@@ -461,21 +437,22 @@ RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[
 #pragma unroll
   for (int r = 0; r < RT_RAYS; ++r)
     mask[r] = 0;
-  for (uint32_t j = 0; j < count; j += 2)
+  for (uint32_t j = 0; j < count; j += RT_PAD)
   {
 #pragma unroll
-    for (uint32_t u = 0; u < 2; ++u)
+    for (uint32_t u = 0; u < RT_PAD; ++u)
     {
       f4 const s = sph[j + u];
       float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
-      float const bound = filter_bound(dx, dy, dz, s.w);
-      float x[RT_RAYS];
+      float const nb = -filter_bound(dx, dy, dz, s.w);
 #pragma unroll
       for (int r = 0; r < RT_RAYS; ++r)
-        x[r] = hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, dx * dir[r].x));
-      push_ge6(mask, x, bound);
+        mask[r] = push_sign(mask[r], hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
     }
   }
+#pragma unroll
+  for (int r = 0; r < RT_RAYS; ++r)
+    mask[r] = chunk_candidates(mask[r], count);
 }
 
 // Takes the candidate with the lowest sphere index out of a chunk mask; returns its index in the chunk.
@@ -510,9 +487,11 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
     for (uint32_t c0 = 0; c0 < tile_count; c0 += RT_CHUNK)
     {
       uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
+      RT_REGION(cnt, 1);
       uint32_t mask = filter_chunk_1(tab + c0, count, dir);
       if (!active)
         mask = 0;
+      RT_REGION(cnt, 2);
       while (env.any_wave(mask != 0u))
       {
         if (mask != 0u)
@@ -527,6 +506,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
           }
         }
       }
+      RT_REGION(cnt, 3);
     }
   }
   if (active)
@@ -551,7 +531,9 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
     {
       uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
       uint32_t mask[RT_RAYS];
+      RT_REGION(cnt, 6);
       filter_chunk_6(sph + c0, count, o, dir, mask);
+      RT_REGION(cnt, 7);
       uint32_t any_mask = 0;
 #pragma unroll
       for (int r = 0; r < RT_RAYS; ++r)
@@ -596,6 +578,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
           }
         }
       }
+      RT_REGION(cnt, 8);
     }
   }
   cnt.filter_tests += (uint32_t)__builtin_popcount(rays_on) * A.n_spheres;
@@ -659,6 +642,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         }
       }
       bool const active = need && L.alive;
+      RT_REGION(cnt, 0);
       if (env.any(active))
       {
         uint32_t const s = L.sx * A.s_row + L.sy;
@@ -695,6 +679,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           }
         }
       }
+      RT_REGION(cnt, 4);
       bool const still = L.alive && !L.has_hit && !L.shading;
       int const n_still = env.count(still);
       if (n_still == 0)
@@ -770,6 +755,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     }
 
     bool const in_pass = L.alive && L.shading;
+    RT_REGION(cnt, 5);
     if (in_pass)
     {
       if (L.li < A.n_lights)
@@ -820,6 +806,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 
     float near_t;
     int near_i;
+    RT_REGION(cnt, 9);
     uint32_t const occluded = trace_pass(A, env, L.hp, dir, a, rays_on, near_t, near_i, cnt);
 
     if (in_pass)
@@ -878,6 +865,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           L.sum = L.sum + accumulate(stack, stride, L.depth);
       }
     }
+    RT_REGION(cnt, 10);
   }
 }
 }  // namespace rtc

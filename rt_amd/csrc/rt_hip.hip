@@ -47,10 +47,12 @@ constexpr uint32_t kStatsWords = 8;
 // counter word sustains well under a hundred dequeues per microsecond, far fewer than the waves ask for).
 // The k-th item of slice r out of g is r + g * k.
 constexpr uint32_t kItemBatch = 64;
+constexpr uint32_t kCancelPoll = 8;
 
 struct ItemPool
 {
   uint32_t next = 0, end = 0;  // wave-uniform
+  uint32_t refills = 0;
 
   __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need)
   {
@@ -66,10 +68,14 @@ struct ItemPool
         uint32_t base = 0;
         if (lane == 0)
         {
-          // A cancelled job stops at the next refill: the wave is sent past the end of the queue.
-          bool const cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+          // A cancelled job stops at a refill: the wave is sent past the end of the queue.  The flag may live
+          // in host memory, a slow read, so only every kCancelPoll-th refill looks at it.
+          bool cancelled = false;
+          if ((refills % kCancelPoll) == 0u)
+            cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
           base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, kItemBatch);
         }
+        refills += 1u;
         next = __builtin_amdgcn_readfirstlane(base);
         end = next + kItemBatch;
       }
@@ -148,13 +154,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
   return v;
 }
 
+#if defined(RT_PROFILE_REGIONS)
+__device__ unsigned long long g_region_ticks[RT_REGION_COUNT];
+#endif
+
 template <bool kTiled>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   f4 * stack = reinterpret_cast<f4 *>(lds_raw);  // [RT_MAX_DEPTH][kBlock]
   f4 * sph = stack + RT_MAX_DEPTH * kBlock;      // resident scene, or the staging tile
-  LaneCounters cnt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  LaneCounters cnt = {};
+#if defined(RT_PROFILE_REGIONS)
+  cnt.last_tick = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (kTiled)
   {
     BlockEnv env{A, sph, ItemPool()};
@@ -195,6 +208,12 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
     atomicAdd(&A.stats[6], (unsigned long long)c6);
     atomicAdd(&A.stats[7], (unsigned long long)c7);
   }
+#if defined(RT_PROFILE_REGIONS)
+  RT_REGION(cnt, 4);
+  if (__lane_id() == 0)
+    for (int k = 0; k < RT_REGION_COUNT; ++k)
+      atomicAdd(&g_region_ticks[k], cnt.region[k]);
+#endif
 }
 
 // The primary-ray filter table: per (padded) sphere, (centre - camera, filter bound).  One thread per entry.
@@ -887,3 +906,19 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
 }
 
 }  // extern "C"
+
+#if defined(RT_PROFILE_REGIONS)
+// Profiling builds only: reads (and clears) the per-region wave clock ticks summed over all waves.
+extern "C" int rt_hip_debug_region_ticks(unsigned long long * out, int count)
+{
+  unsigned long long host[RT_REGION_COUNT] = {0};
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_region_ticks), sizeof(host)) != hipSuccess)
+    return RT_HIP_ERR_DEVICE;
+  for (int k = 0; k < count && k < RT_REGION_COUNT; ++k)
+    out[k] = host[k];
+  unsigned long long const zero[RT_REGION_COUNT] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_region_ticks), zero, sizeof(zero)) != hipSuccess)
+    return RT_HIP_ERR_DEVICE;
+  return RT_HIP_OK;
+}
+#endif

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -10,7 +11,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kIters = 4096;
 constexpr int kChains = 8;
 
-enum Op { FMA, PKFMA, MULHI, MULLO, MAD64, SQRT, RCP, RSQ, CMPSEL, PHILOX, ADD, EXP2, SINREV };
+enum Op { FMA, PKFMA, MULHI, MULLO, MAD64, SQRT, RCP, RSQ, CMPSEL, PHILOX, ADD, EXP2, SINREV, CMPADDC, ALIGNBIT, FILT_OLD, FILT_NEW, SFMA };
 
 template <int OP>
 __global__ __launch_bounds__(256) void bench(float * out, float seed)
@@ -46,6 +47,13 @@ __global__ __launch_bounds__(256) void bench(float * out, float seed)
       if (OP == EXP2) x[i] = __builtin_amdgcn_exp2f(x[i]) * b;
       if (OP == SINREV) x[i] = __builtin_amdgcn_sinf(x[i]) + a;
       if (OP == CMPSEL) x[i] = (x[i] >= a && x[i] < b) ? x[i] * a : b;
+      if (OP == ALIGNBIT) u[i] = __builtin_amdgcn_alignbit(u[i], __float_as_uint(x[i]), 31);
+      if (OP == FILT_NEW)
+      {
+        float const t = __builtin_fmaf(x[i], a, __builtin_fmaf(x[i], b, __builtin_fmaf(x[i], seed, -b)));
+        u[i] = __builtin_amdgcn_alignbit(u[i], __float_as_uint(t), 31);
+      }
+      if (OP == SFMA) x[i] = __builtin_fmaf(x[i], a, x[(i + 1) % kChains]);
       if (OP == PHILOX)
       {
         uint32_t c0 = u[i], c1 = it, c2 = i, c3 = 0, k0 = threadIdx.x, k1 = 7;
@@ -59,6 +67,35 @@ __global__ __launch_bounds__(256) void bench(float * out, float seed)
         }
         u[i] = c0 ^ c1 ^ c2 ^ c3;
       }
+    }
+    if (OP == CMPADDC || OP == FILT_OLD)
+    {
+      float t[kChains];
+#pragma unroll
+      for (int i = 0; i < kChains; ++i)
+        t[i] = (OP == FILT_OLD) ? __builtin_fmaf(x[i], a, __builtin_fmaf(x[i], b, x[i] * seed)) : x[i];
+      unsigned long long c0, c1, c2, c3, c4, c5, c6, c7;
+      asm("v_cmp_ge_f32_e64 %[c0], %[x0], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c1], %[x1], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c2], %[x2], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c3], %[x3], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c4], %[x4], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c5], %[x5], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c6], %[x6], %[b]\n\t"
+          "v_cmp_ge_f32_e64 %[c7], %[x7], %[b]\n\t"
+          "v_addc_co_u32_e64 %[m0], %[c0], %[m0], %[m0], %[c0]\n\t"
+          "v_addc_co_u32_e64 %[m1], %[c1], %[m1], %[m1], %[c1]\n\t"
+          "v_addc_co_u32_e64 %[m2], %[c2], %[m2], %[m2], %[c2]\n\t"
+          "v_addc_co_u32_e64 %[m3], %[c3], %[m3], %[m3], %[c3]\n\t"
+          "v_addc_co_u32_e64 %[m4], %[c4], %[m4], %[m4], %[c4]\n\t"
+          "v_addc_co_u32_e64 %[m5], %[c5], %[m5], %[m5], %[c5]\n\t"
+          "v_addc_co_u32_e64 %[m6], %[c6], %[m6], %[m6], %[c6]\n\t"
+          "v_addc_co_u32_e64 %[m7], %[c7], %[m7], %[m7], %[c7]"
+          : [m0] "+v"(u[0]), [m1] "+v"(u[1]), [m2] "+v"(u[2]), [m3] "+v"(u[3]), [m4] "+v"(u[4]), [m5] "+v"(u[5]),
+            [m6] "+v"(u[6]), [m7] "+v"(u[7]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3),
+            [c4] "=&s"(c4), [c5] "=&s"(c5), [c6] "=&s"(c6), [c7] "=&s"(c7)
+          : [x0] "v"(t[0]), [x1] "v"(t[1]), [x2] "v"(t[2]), [x3] "v"(t[3]), [x4] "v"(t[4]), [x5] "v"(t[5]),
+            [x6] "v"(t[6]), [x7] "v"(t[7]), [b] "v"(b));
     }
   }
   float acc = 0.0f;
@@ -85,12 +122,14 @@ void run(const char * name, double ops_per_call, int blocks, float * d_out)
   printf("%-8s %8.3f ms  %8.2f Tlane-op/s\n", name, ms, lane_ops / (ms * 1e-3) / 1e12);
 }
 
-int main()
+int main(int argc, char ** argv)
 {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   printf("device %s %s CUs %d clock %d kHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
-  int const blocks = prop.multiProcessorCount * 8;
+  int const per_cu = argc > 1 ? atoi(argv[1]) : 8;  // blocks of 4 waves per CU = waves per SIMD
+  int const blocks = prop.multiProcessorCount * per_cu;
+  printf("waves per SIMD %d\n", per_cu);
   float * d_out;
   hipMalloc(&d_out, (size_t)blocks * 256 * sizeof(float));
   run<FMA>("fma", 1, blocks, d_out);
@@ -106,6 +145,11 @@ int main()
   run<SINREV>("sin+add", 1, blocks, d_out);
   run<CMPSEL>("cmpsel", 1, blocks, d_out);
   run<PHILOX>("philox", 1, blocks, d_out);
+  run<CMPADDC>("cmp+addc", 2, blocks, d_out);
+  run<ALIGNBIT>("alignbit", 1, blocks, d_out);
+  run<FILT_OLD>("filt_old", 5, blocks, d_out);
+  run<FILT_NEW>("filt_new", 4, blocks, d_out);
+  run<SFMA>("fma_dep", 1, blocks, d_out);
   hipFree(d_out);
   return 0;
 }
