@@ -51,7 +51,8 @@ constexpr uint32_t RT_MAX_DEPTH = 10;  // demos/demo_frame_cpu.cpp:10
 constexpr float RT_EPS = 1e-5f;        // ray_tracing/types.hpp:9
 constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
-constexpr uint32_t RT_PAD = 4;         // sphere arrays are padded to a multiple of this with never-hit entries
+constexpr uint32_t RT_PAD = 1;         // sphere arrays are padded to a multiple of this with never-hit entries
+constexpr uint32_t RT_UNROLL = 4;      // spheres per trip of the filter loops' main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
 
@@ -191,6 +192,11 @@ struct TraceArgs
   // frame
   uint32_t width, height, s_row, s_count;  // s_count = s_row * s_row
   uint32_t flags, seed, max_depth, slice_index, slice_count;
+  // Column masks (small resident scenes): the primary-ray filter runs once per sub-sample column, against the
+  // column's middle direction, with every bound of the camera table lowered by |centre - camera| * col_delta;
+  // col_delta bounds the distance between the middle direction and any sample direction of a column.
+  uint32_t column_masks;      // 0: filter every primary ray on its own (col_delta is 0 then)
+  float col_delta;
   // outputs
   float * partial;            // 3 planes of n_items column sums: partial[c * n_items + pixel * s_row + sx]
   uint32_t n_items;           // width * height * s_row
@@ -267,7 +273,10 @@ struct Lane
   float sdx, dyp;   // sdx of the column, dy of the pixel (ray_tracing/frame.cpp:49,52,58)
   f3 sum;
   bool alive, need_item;
+  uint32_t cm0, cm1;  // candidate masks of the column (spheres 0..31, 32..63) when column masks are on
   // current path
+  f3 acc_l;           // forward accumulation: product of the l entries pushed so far
+  float acc_e;        // ... and of emissivity_k ^ k
   uint32_t sample;  // sample index (RNG key)
   uint32_t depth;   // entries pushed so far ("scatterResultsCount")
   bool has_hit;     // a hit waits to be shaded
@@ -303,6 +312,52 @@ RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
   float const dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;  // frame.cpp:52
   L.sdx = dxp + A.cell_x * (float)sx / (float)A.s_row;                 // frame.cpp:58
   L.sum = mk3(0.0f, 0.0f, 0.0f);
+}
+
+// What an environment hands out with a work item.  When `prepared`, the column's ray set-up and candidate
+// masks were computed ahead (prepare_column); otherwise the lane runs begin_item itself.
+struct ItemInfo
+{
+  uint32_t item;          // RT_INVALID: the slice is used up
+  bool prepared;
+  float sdx, dyp;
+  uint32_t cm0, cm1, pixel, sx;
+  uint32_t filter_tests;  // filter tests this lane executed while preparing columns (for anyone)
+};
+
+struct ColumnEntry
+{
+  float sdx, dyp;
+  uint32_t cm0, cm1, pixel, sx, pad0, pad1;
+};
+
+// Filter of one ray against `count` (<= RT_CHUNK) camera-table entries; defined below.
+RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir);
+
+// Ray set-up of one column (the arithmetic of begin_item) and its candidate masks: the camera table, whose
+// bounds were lowered for this purpose, filtered with the direction through the middle of the column.
+// camtab: all A.n_padded (<= 64) entries.
+RT_FN ColumnEntry prepare_column(const TraceArgs & A, const f4 * camtab, uint32_t item)
+{
+  ColumnEntry e;
+  uint32_t const pixel = item / A.s_row;
+  uint32_t const sx = item - pixel * A.s_row;
+  uint32_t const y = pixel / A.width;
+  uint32_t const x = pixel - y * A.width;
+  e.pixel = pixel;
+  e.sx = sx;
+  e.dyp = (-2.0f * (float)y / (float)A.height + 1.0f) * A.dh;
+  float const dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;
+  e.sdx = dxp + A.cell_x * (float)sx / (float)A.s_row;
+  float const mid = 0.5f * (float)(A.s_row - 1u) / (float)A.s_row;
+  float const sdy = e.dyp - A.cell_y * mid;
+  f3 const v = (A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * e.sdx;
+  f3 const dc = normalize3_fast(v);
+  uint32_t const c0 = (A.n_padded < RT_CHUNK) ? A.n_padded : RT_CHUNK;
+  e.cm0 = filter_chunk_1(camtab, c0, dc);
+  e.cm1 = (A.n_padded > RT_CHUNK) ? filter_chunk_1(camtab + RT_CHUNK, A.n_padded - RT_CHUNK, dc) : 0u;
+  e.pad0 = e.pad1 = 0u;
+  return e;
 }
 
 // Material::Scatter for the three materials, ray_tracing/default_materials.cpp:11-67.
@@ -405,6 +460,47 @@ RT_FN void push(f4 * stack, uint32_t stride, uint32_t depth, f3 l, float e)
   stack[depth * stride] = s;
 }
 
+// e^k for k < 16 by squaring.
+RT_FN float pow_small(float e, uint32_t k)
+{
+  float p = (k & 1u) ? e : 1.0f;
+  float b = e * e;
+  p = (k & 2u) ? p * b : p;
+  b = b * b;
+  p = (k & 4u) ? p * b : p;
+  b = b * b;
+  p = (k & 8u) ? p * b : p;
+  return p;
+}
+
+// Entry `depth` of a path.  kForward: the reverse loop of demos/demo_frame_cpu.cpp:60-75 multiplies
+// l_i * (e_{i+1} ... e_{n-1}) over all entries, which is prod(l_i) * prod(e_k ^ k) when its early exit
+// (|rest| < kEps) cannot trigger -- the host decides that per scene from the materials' emissivities -- so
+// two running products replace the stack.  Otherwise the entries go to the lane's stack and path_colour
+// replays the loop as written.
+template <bool kForward>
+RT_FN void path_push(Lane & L, f4 * stack, uint32_t stride, f3 l, float e)
+{
+  if constexpr (kForward)
+  {
+    L.acc_l = (L.depth == 0u) ? l : L.acc_l * l;
+    float const ek = pow_small(e, L.depth);
+    L.acc_e = (L.depth == 0u) ? 1.0f : L.acc_e * ek;
+  }
+  else
+    push(stack, stride, L.depth, l, e);
+  L.depth += 1;
+}
+
+template <bool kForward>
+RT_FN f3 path_colour(const Lane & L, const f4 * stack, uint32_t stride)
+{
+  if constexpr (kForward)
+    return (L.acc_l * L.acc_e) * 0.5f;
+  else
+    return accumulate(stack, stride, L.depth);
+}
+
 // The filter keeps its outcome as the sign of dot(d, D) - bound, accumulated in one FMA chain that starts from
 // -bound, and shifts that sign bit into the lane's mask: a set bit means "rejected".  chunk_candidates turns
 // the `count` bits shifted in into the candidate mask (entry j of the chunk in bit count - 1 - j).
@@ -419,16 +515,32 @@ RT_FN uint32_t chunk_candidates(uint32_t rejected, uint32_t count)
 RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
 {
   uint32_t mask = 0;
-  for (uint32_t j = 0; j < count; j += RT_PAD)
+  uint32_t j = 0;
+  for (; j + RT_UNROLL <= count; j += RT_UNROLL)
   {
 #pragma unroll
-    for (uint32_t u = 0; u < RT_PAD; ++u)
+    for (uint32_t u = 0; u < RT_UNROLL; ++u)
     {
       f4 const e = tab[j + u];
       mask = push_sign(mask, hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, hw_fma(e.x, dir.x, -e.w))));
     }
   }
+  for (; j < count; ++j)
+  {
+    f4 const e = tab[j];
+    mask = push_sign(mask, hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, hw_fma(e.x, dir.x, -e.w))));
+  }
   return chunk_candidates(mask, count);
+}
+
+// One sphere against RT_RAYS rays with a common origin.
+RT_FN void filter_sphere_6(f4 s, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask)[RT_RAYS])
+{
+  float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
+  float const nb = -filter_bound(dx, dy, dz, s.w);
+#pragma unroll
+  for (int r = 0; r < RT_RAYS; ++r)
+    mask[r] = push_sign(mask[r], hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
 }
 
 // Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK, a multiple of RT_PAD) spheres.
@@ -437,19 +549,15 @@ RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[
 #pragma unroll
   for (int r = 0; r < RT_RAYS; ++r)
     mask[r] = 0;
-  for (uint32_t j = 0; j < count; j += RT_PAD)
+  uint32_t j = 0;
+  for (; j + RT_UNROLL <= count; j += RT_UNROLL)
   {
 #pragma unroll
-    for (uint32_t u = 0; u < RT_PAD; ++u)
-    {
-      f4 const s = sph[j + u];
-      float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
-      float const nb = -filter_bound(dx, dy, dz, s.w);
-#pragma unroll
-      for (int r = 0; r < RT_RAYS; ++r)
-        mask[r] = push_sign(mask[r], hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
-    }
+    for (uint32_t u = 0; u < RT_UNROLL; ++u)
+      filter_sphere_6(sph[j + u], o, dir, mask);
   }
+  for (; j < count; ++j)
+    filter_sphere_6(sph[j], o, dir, mask);
 #pragma unroll
   for (int r = 0; r < RT_RAYS; ++r)
     mask[r] = chunk_candidates(mask[r], count);
@@ -468,17 +576,50 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //                     sphere tiles are re-staged inside the loop)
 //   count(p)          number of such lanes for which p holds
 //   any_wave(p)       true if p holds for any lane of the wave
-//   fetch_item(need)  hands a fresh work item to each lane that asks (RT_INVALID when the slice is used up)
-//   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i)
+//   fetch_item(need, info)  hands a fresh work item to each lane that asks (info.item == RT_INVALID when the
+//                     slice is used up), prepared or not (see ItemInfo)
+//   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i);  material(m, k) and
+//                     light(l, k): record k (0 or 1) of material m / light l
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
 //                     tile_data(primary)
 template <class Env>
-RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, float a, float & best_t,
-                         int & best_i, LaneCounters & cnt)
+RT_FN void resolve_primary(const TraceArgs & A, Env & env, uint32_t mask, uint32_t base, uint32_t count, f3 dir,
+                           float a, float & best_t, int & best_i, LaneCounters & cnt)
+{
+  while (env.any_wave(mask != 0u))
+  {
+    if (mask != 0u)
+    {
+      int const i = (int)(base + pop_candidate(mask, count));
+      float t;
+      cnt.exact_tests += 1;
+      if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t) && (best_i < 0 || t < best_t))
+      {
+        best_i = i;
+        best_t = t;
+      }
+    }
+  }
+}
+
+// cm0, cm1: the column's candidate masks, used instead of a filter pass when A.column_masks is set.
+template <class Env>
+RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, float a, uint32_t cm0, uint32_t cm1,
+                         float & best_t, int & best_i, LaneCounters & cnt)
 {
   best_i = -1;
   best_t = 0.0f;
+  if (A.column_masks != 0u)
+  {
+    uint32_t const c0 = (A.n_padded < RT_CHUNK) ? A.n_padded : RT_CHUNK;
+    RT_REGION(cnt, 2);
+    resolve_primary(A, env, active ? cm0 : 0u, 0u, c0, dir, a, best_t, best_i, cnt);
+    if (A.n_padded > RT_CHUNK)
+      resolve_primary(A, env, active ? cm1 : 0u, RT_CHUNK, A.n_padded - RT_CHUNK, dir, a, best_t, best_i, cnt);
+    RT_REGION(cnt, 3);
+    return;
+  }
   for (uint32_t k = 0; k < env.tiles(); ++k)
   {
     uint32_t const tile_count = env.load_tile(k, true);
@@ -492,20 +633,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
       if (!active)
         mask = 0;
       RT_REGION(cnt, 2);
-      while (env.any_wave(mask != 0u))
-      {
-        if (mask != 0u)
-        {
-          int const i = (int)(tile_base + c0 + pop_candidate(mask, count));
-          float t;
-          cnt.exact_tests += 1;
-          if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t) && (best_i < 0 || t < best_t))
-          {
-            best_i = i;
-            best_t = t;
-          }
-        }
-      }
+      resolve_primary(A, env, mask, tile_base + c0, count, dir, a, best_t, best_i, cnt);
       RT_REGION(cnt, 3);
     }
   }
@@ -585,10 +713,13 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
   return (rays_on & ~live) & ((1u << RT_LIGHT_SAMPLES) - 1u);
 }
 
-template <class Env>
+template <bool kForward, class Env>
 RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t stride, LaneCounters & cnt)
 {
   Lane L;
+  L.cm0 = L.cm1 = 0u;
+  L.acc_l = mk3(0.0f, 0.0f, 0.0f);
+  L.acc_e = 1.0f;
   L.alive = true;
   L.need_item = true;
   L.has_hit = false;
@@ -629,14 +760,29 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       bool const ask = need && L.need_item;
       if (env.any(ask))
       {
-        uint32_t const q = env.fetch_item(ask);
+        ItemInfo info;
+        env.fetch_item(ask, info);
+        cnt.filter_tests += info.filter_tests;
         if (ask)
         {
-          if (q == RT_INVALID)
+          if (info.item == RT_INVALID)
             L.alive = false;
           else
           {
-            begin_item(A, L, q);
+            if (info.prepared)
+            {
+              L.item = info.item;
+              L.pixel = info.pixel;
+              L.sx = info.sx;
+              L.sy = 0;
+              L.sdx = info.sdx;
+              L.dyp = info.dyp;
+              L.cm0 = info.cm0;
+              L.cm1 = info.cm1;
+              L.sum = mk3(0.0f, 0.0f, 0.0f);
+            }
+            else
+              begin_item(A, L, info.item);
             L.need_item = false;
           }
         }
@@ -655,7 +801,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         float const a = dot3(d, d);
         float t;
         int hi;
-        trace_primary(A, env, active, d, a, t, hi, cnt);
+        trace_primary(A, env, active, d, a, L.cm0, L.cm1, t, hi, cnt);
         if (active)
         {
           cnt.samples += 1;
@@ -710,8 +856,8 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     {
       // A new hit: Material::Scatter first (demos/demo_frame_cpu.cpp:38).
       uint32_t const mi = env.sphere_material(L.hidx);
-      f4 const m0 = A.materials[2u * mi];
-      f4 const m1 = A.materials[2u * mi + 1u];
+      f4 const m0 = env.material(mi, 0u);
+      f4 const m1 = env.material(mi, 1u);
       uint32_t const mtype = f2u(m1.y);
       L.m_albedo = mk3(m0.x, m0.y, m0.z);
       float const m_rough = m0.w;
@@ -731,17 +877,16 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       {
         // Absorbed: the entry becomes the environment colour and the path ends
         // (demos/demo_frame_cpu.cpp:39-45).
-        push(stack, stride, L.depth, A.background, 1.0f);
-        L.depth += 1;
-        L.sum = L.sum + accumulate(stack, stride, L.depth);
+        path_push<kForward>(L, stack, stride, A.background, 1.0f);
+        L.sum = L.sum + path_colour<kForward>(L, stack, stride);
       }
       else
       {
         L.spec = mk3(0.0f, 0.0f, 0.0f);
         for (uint32_t li = 0; li < A.n_lights; ++li)
         {
-          f4 const l0 = A.lights[2u * li];
-          f4 const l1 = A.lights[2u * li + 1u];
+          f4 const l0 = env.light(li, 0u);
+          f4 const l1 = env.light(li, 1u);
           L.spec = L.spec + specular(mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), L.m_albedo, m_rough,
                                      L.m_refraction, L.hd, L.hn);
         }
@@ -760,7 +905,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     {
       if (L.li < A.n_lights)
       {
-        f4 const l0 = A.lights[2u * L.li];
+        f4 const l0 = env.light(L.li, 0u);
         f3 const to_light = mk3(-l0.x, -l0.y, -l0.z);
         f3 jit[RT_LIGHT_SAMPLES];
 #pragma unroll
@@ -814,7 +959,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       if (L.li < A.n_lights)
       {
         // DirectionalLight::TraceLight, ray_tracing/directional_light.cpp:15-35.
-        f4 const l1 = A.lights[2u * L.li + 1u];
+        f4 const l1 = env.light(L.li, 1u);
         f3 const lcol = mk3(l1.x, l1.y, l1.z);
         // An occluded sample is tinted by the shaded surface's own material.
         f3 const tint = mix3(L.m_albedo, lcol, 0.75f) * (L.m_refraction * 0.75f);
@@ -839,8 +984,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       {
         // l = attenuation + diffuse + specular (demos/demo_frame_cpu.cpp:66); every material's
         // attenuation is its albedo (ray_tracing/default_materials.cpp:14,26,40).
-        push(stack, stride, L.depth, (L.m_albedo + L.diffuse) + L.spec, L.e);
-        L.depth += 1;
+        path_push<kForward>(L, stack, stride, (L.m_albedo + L.diffuse) + L.spec, L.e);
         cnt.shaded += 1;
         L.shading = false;
         bool ended = true;
@@ -862,7 +1006,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           }
         }
         if (ended)
-          L.sum = L.sum + accumulate(stack, stride, L.depth);
+          L.sum = L.sum + path_colour<kForward>(L, stack, stride);
       }
     }
     RT_REGION(cnt, 10);

@@ -1,20 +1,22 @@
 // rt_hip.hip -- gfx950 kernels and the C ABI of the MI355X ray-tracing backend (include/rt_hip.h).
 //
 // Kernels
-//   trace_kernel<false>  persistent waves; the whole scene (<= kResidentSpheres spheres) sits in LDS for the
-//                        life of the block; every lane runs the path state machine of rt_core.h and pulls
-//                        pixels from one frame-wide atomic counter, 64 lanes per atomic (ballot + prefix
-//                        count).  Waves never wait for each other.
-//   trace_kernel<true>   the same loop for larger scenes: the block re-stages the spheres through LDS in
+//   trace_kernel<false, *>  persistent waves; the whole scene (<= kResidentSpheres spheres) sits in LDS for
+//                        the life of the block; every lane runs the path state machine of rt_core.h and
+//                        takes sub-sample columns from one frame-wide atomic counter, a batch of 64 per
+//                        atomic.  Waves never wait for each other.
+//   trace_kernel<true, *>   the same loop for larger scenes: the block re-stages the spheres through LDS in
 //                        tiles of kTileSpheres inside every ray pass, so its waves stay in step.
+//   trace_kernel<*, true>   paths accumulated forward in registers; <*, false> keeps the reference's reverse
+//                        loop over a 10-entry stack per lane in LDS (40 KB per block).
 //   colsum_kernel        accumulate pass: per pixel, the column sums of the slice -> planar pixel sums.
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
 //                        16 bytes per lane per access.  These two are the HBM-bound passes.
 //
 //   camtab_kernel        per-frame table of the primary-ray filter, one entry per sphere.
 //
-// LDS per block: 10 x float4 path stack per lane (40 KB at 256 lanes) + the resident scene and its camera
-// table (48 B per sphere), or one 16 KB staging tile for scenes above kResidentSpheres spheres.
+// LDS per block: the resident scene (48 B per sphere, 32 B per material and light) and 8 KB of prepared
+// columns, or one 16 KB staging tile for scenes above kResidentSpheres spheres.
 #include "rt_core.h"
 #include "rt_hip.h"
 #include "rt_prep.h"
@@ -35,7 +37,14 @@ namespace
 using namespace rtc;
 
 constexpr int kBlock = 256;               // 4 waves
-constexpr int kWavesPerSimd = 3;          // blocks per CU the register budget is sized for
+constexpr int kWavesPerSimd = 3;          // blocks per CU the register budget is sized for (path stacks in LDS)
+// Without the stacks a fourth wave per SIMD would fit (and is about 1 % faster), but four waves of 128
+// registers fill the register file, and the snapshot kernels of a running job could then not start before
+// the frame is over; three waves leave them room.
+constexpr int kWavesPerSimdForward = 3;
+constexpr uint32_t kResidentMaterials = 256;  // resident scenes also keep their materials and lights in LDS
+constexpr uint32_t kResidentLights = 16;
+constexpr uint32_t kColumnMaskSpheres = 64;   // column masks: two 32-bit words per lane
 constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS whole (48 B per sphere)
 constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
 constexpr uint32_t kStatsWords = 8;
@@ -54,6 +63,24 @@ struct ItemPool
   uint32_t next = 0, end = 0;  // wave-uniform
   uint32_t refills = 0;
 
+  // Reserves the next batch of queue positions for the wave.
+  __device__ __forceinline__ void refill(const TraceArgs & A)
+  {
+    uint32_t base = 0;
+    if (__lane_id() == 0)
+    {
+      // A cancelled job stops at a refill: the wave is sent past the end of the queue.  The flag may live
+      // in host memory, a slow read, so only every kCancelPoll-th refill looks at it.
+      bool cancelled = false;
+      if ((refills % kCancelPoll) == 0u)
+        cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+      base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, kItemBatch);
+    }
+    refills += 1u;
+    next = __builtin_amdgcn_readfirstlane(base);
+    end = next + kItemBatch;
+  }
+
   __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need)
   {
     uint32_t result = RT_INVALID;
@@ -64,21 +91,7 @@ struct ItemPool
       if (mask == 0ull)
         break;
       if (next == end)
-      {
-        uint32_t base = 0;
-        if (lane == 0)
-        {
-          // A cancelled job stops at a refill: the wave is sent past the end of the queue.  The flag may live
-          // in host memory, a slow read, so only every kCancelPoll-th refill looks at it.
-          bool cancelled = false;
-          if ((refills % kCancelPoll) == 0u)
-            cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-          base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, kItemBatch);
-        }
-        refills += 1u;
-        next = __builtin_amdgcn_readfirstlane(base);
-        end = next + kItemBatch;
-      }
+        refill(A);
       uint32_t const avail = end - next;
       uint32_t const wanted = (uint32_t)__popcll(mask);
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -99,21 +112,83 @@ struct ItemPool
 struct WaveEnv
 {
   const TraceArgs & A;
-  const f4 * filt;   // LDS: n_padded filter records
-  const f4 * cam;    // LDS: n_padded camera-table records
-  const f4 * exact;  // LDS: n_padded exact records
+  const f4 * filt;       // LDS: n_padded filter records
+  const f4 * cam;        // LDS: n_padded camera-table records
+  const f4 * exact;      // LDS: n_padded exact records
+  const f4 * mats;       // LDS: 2 * n_materials
+  const f4 * lights;     // LDS: 2 * n_lights
+  ColumnEntry * batch;   // LDS: this wave's kItemBatch prepared columns (column masks only)
   ItemPool pool;
 
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
-  __device__ __forceinline__ uint32_t fetch_item(bool need) { return pool.fetch(A, need); }
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[2u * m + k]; }
+  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return lights[2u * l + k]; }
   __device__ __forceinline__ uint32_t tiles() const { return 1u; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return A.n_padded; }
   __device__ __forceinline__ const f4 * tile_data(bool primary) const { return primary ? cam : filt; }
+
+  // With column masks the wave prepares a whole batch when it reserves one: lane l sets up the column at
+  // queue position base + l (ray set-up and candidate masks, one filter pass per column instead of one per
+  // sample) and parks it in the wave's LDS table, from where the lanes pick their items up.
+  __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
+  {
+    info.item = RT_INVALID;
+    info.prepared = false;
+    info.filter_tests = 0u;
+    if (A.column_masks == 0u)
+    {
+      info.item = pool.fetch(A, need);
+      return;
+    }
+    uint32_t const lane = __lane_id();
+    for (;;)
+    {
+      unsigned long long const mask = __ballot(need);
+      if (mask == 0ull)
+        break;
+      if (pool.next == pool.end)
+      {
+        pool.refill(A);
+        unsigned long long const q = (unsigned long long)A.slice_index +
+                                     (unsigned long long)A.slice_count * (unsigned long long)(pool.next + lane);
+        ColumnEntry e;
+        e.pixel = RT_INVALID;
+        if (q < (unsigned long long)A.n_items)
+        {
+          e = prepare_column(A, cam, (uint32_t)q);
+          info.filter_tests += A.n_spheres;
+        }
+        batch[lane] = e;
+        __builtin_amdgcn_wave_barrier();
+      }
+      uint32_t const avail = pool.end - pool.next;
+      uint32_t const wanted = (uint32_t)__popcll(mask);
+      uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (need && rank < avail)
+      {
+        uint32_t const slot = pool.next + rank - (pool.end - kItemBatch);
+        ColumnEntry const e = batch[slot];
+        if (e.pixel != RT_INVALID)
+        {
+          info.item = e.pixel * A.s_row + e.sx;
+          info.prepared = true;
+          info.sdx = e.sdx;
+          info.dyp = e.dyp;
+          info.cm0 = e.cm0;
+          info.cm1 = e.cm1;
+          info.pixel = e.pixel;
+          info.sx = e.sx;
+        }
+        need = false;
+      }
+      pool.next += wanted < avail ? wanted : avail;
+    }
+  }
 };
 
 // Larger scenes: the block re-stages the spheres (or the camera table) through one LDS tile inside every
@@ -127,9 +202,16 @@ struct BlockEnv
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
-  __device__ __forceinline__ uint32_t fetch_item(bool need) { return pool.fetch(A, need); }
+  __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
+  {
+    info.prepared = false;
+    info.filter_tests = 0u;
+    info.item = pool.fetch(A, need);
+  }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[2u * m + k]; }
+  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
   __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + A.tile_size - 1u) / A.tile_size; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * A.tile_size; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t k, bool primary) const
@@ -158,12 +240,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 __device__ unsigned long long g_region_ticks[RT_REGION_COUNT];
 #endif
 
-template <bool kTiled>
-__global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs A)
+// LDS layout: [path stacks, unless kForward][resident: filter, camera table, exact records, materials, lights,
+// prepared-column tables | tiled: one staging tile].
+template <bool kTiled, bool kForward>
+__global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  f4 * stack = reinterpret_cast<f4 *>(lds_raw);  // [RT_MAX_DEPTH][kBlock]
-  f4 * sph = stack + RT_MAX_DEPTH * kBlock;      // resident scene, or the staging tile
+  f4 * stack = reinterpret_cast<f4 *>(lds_raw);                    // [RT_MAX_DEPTH][kBlock]
+  f4 * sph = stack + (kForward ? 0u : RT_MAX_DEPTH * kBlock);      // resident scene, or the staging tile
   LaneCounters cnt = {};
 #if defined(RT_PROFILE_REGIONS)
   cnt.last_tick = __builtin_amdgcn_s_memtime();
@@ -171,21 +255,28 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
   if constexpr (kTiled)
   {
     BlockEnv env{A, sph, ItemPool()};
-    trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    trace_loop<kForward>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
   {
     f4 * cam = sph + A.n_padded;
     f4 * exact = cam + A.n_padded;
+    f4 * mats = exact + A.n_padded;
+    f4 * lights = mats + 2u * A.n_materials;
+    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(lights + 2u * A.n_lights);
     for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
     {
       sph[i] = A.filter[i];
       cam[i] = A.camtab[i];
       exact[i] = A.spheres[i];
     }
+    for (uint32_t i = threadIdx.x; i < 2u * A.n_materials; i += kBlock)
+      mats[i] = A.materials[i];
+    for (uint32_t i = threadIdx.x; i < 2u * A.n_lights; i += kBlock)
+      lights[i] = A.lights[i];
     __syncthreads();
-    WaveEnv env{A, sph, cam, exact, ItemPool()};
-    trace_loop(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    WaveEnv env{A, sph, cam, exact, mats, lights, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
+    trace_loop<kForward>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
 
   // Work counters: one 64-bit atomic per wave and counter.
@@ -218,7 +309,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel(TraceArgs 
 
 // The primary-ray filter table: per (padded) sphere, (centre - camera, filter bound).  One thread per entry.
 __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ filter, f4 * __restrict__ camtab,
-                                                     uint32_t n_padded, f3 cam_pos)
+                                                     uint32_t n_padded, f3 cam_pos, float col_delta)
 {
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_padded)
@@ -229,7 +320,9 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
   e.x = dx;
   e.y = dy;
   e.z = dz;
-  e.w = filter_bound(dx, dy, dz, s.w);
+  // With column masks the bound is lowered by |d| * col_delta (rounded up), see TraceArgs::col_delta.
+  float const len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f;
+  e.w = filter_bound(dx, dy, dz, s.w) - len * col_delta;
   camtab[i] = e;
 }
 
@@ -337,6 +430,7 @@ struct rt_hip_scene
   f4 * d_materials = nullptr;
   f4 * d_lights = nullptr;
   uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
+  bool forward_ok = false;  // paths can be accumulated forward (rt_prep.h forward_accumulation_ok)
 };
 
 struct rt_hip_job
@@ -353,8 +447,9 @@ struct rt_hip_job
 
 namespace
 {
-// RT_HIP_FORCE_TILE=n (a multiple of 4, at most kTileSpheres) makes every scene take the staged path with
-// tiles of n records; a testing aid for exercising that path on small scenes.
+// RT_HIP_FORCE_TILE=n (at most kTileSpheres) makes every scene take the staged path with tiles of n records;
+// RT_HIP_FORCE_STACK (any value) makes every scene created afterwards keep its paths on the LDS stack.  Both
+// are testing aids for exercising those paths on the small demo scenes.
 uint32_t forced_tile()
 {
   const char * v = std::getenv("RT_HIP_FORCE_TILE");
@@ -364,26 +459,48 @@ uint32_t forced_tile()
   return std::min(std::max(n, RT_PAD), kTileSpheres);
 }
 
-bool is_tiled(uint32_t n_padded) { return n_padded > kResidentSpheres || forced_tile() != 0u; }
-uint32_t tile_size() { return forced_tile() ? forced_tile() : kTileSpheres; }
-
-// Path stacks + either the resident scene (filter, camera table and exact records) or one staging tile.
-size_t lds_bytes(uint32_t n_padded)
+bool is_tiled(const rt_hip_scene * sc)
 {
-  uint32_t const entries = is_tiled(n_padded) ? kTileSpheres : std::max(3u * n_padded, 1u);
-  return sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock + entries);
+  return sc->n_padded > kResidentSpheres || sc->n_materials > kResidentMaterials || sc->n_lights > kResidentLights ||
+         forced_tile() != 0u;
+}
+uint32_t tile_size() { return forced_tile() ? forced_tile() : kTileSpheres; }
+bool uses_column_masks(const rt_hip_scene * sc)
+{
+  return !is_tiled(sc) && sc->n_padded > 0u && sc->n_padded <= kColumnMaskSpheres;
+}
+
+// Path stacks (scenes whose paths cannot be accumulated forward) + either the resident scene (filter, camera
+// table, exact records, materials, lights, one prepared-column table per wave) or one staging tile.
+size_t lds_bytes(const rt_hip_scene * sc)
+{
+  size_t bytes = sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock);
+  if (is_tiled(sc))
+    bytes += sizeof(f4) * (size_t)kTileSpheres;
+  else
+    bytes += sizeof(f4) * (size_t)(3u * sc->n_padded + 2u * sc->n_materials + 2u * sc->n_lights) +
+             sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
+  return std::max<size_t>(bytes, 16u);
+}
+
+template <class Launch>
+auto with_trace_kernel(const rt_hip_scene * sc, Launch && go)
+{
+  bool const tiled = is_tiled(sc);
+  if (tiled)
+    return sc->forward_ok ? go(trace_kernel<true, true>) : go(trace_kernel<true, false>);
+  return sc->forward_ok ? go(trace_kernel<false, true>) : go(trace_kernel<false, false>);
 }
 
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
-// more lanes than pixels.
-int persistent_blocks(uint32_t n_padded, unsigned long long items)
+// more lanes than work items.
+int persistent_blocks(const rt_hip_scene * sc, unsigned long long items)
 {
   int per_cu = 0;
-  hipError_t e;
-  if (is_tiled(n_padded))
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true>, kBlock, lds_bytes(n_padded));
-  else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false>, kBlock, lds_bytes(n_padded));
+  size_t const lds = lds_bytes(sc);
+  hipError_t const e = with_trace_kernel(sc, [&](auto kernel) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds);
+  });
   if (e != hipSuccess || per_cu < 1)
     per_cu = 1;
   long long blocks = (long long)per_cu * std::max(g_lib.compute_units, 1);
@@ -440,23 +557,24 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
 
   RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
+  a.column_masks = uses_column_masks(scene) ? 1u : 0u;
+  a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
   if (scene->n_padded > 0)
   {
     int const tab_blocks = (int)((scene->n_padded + 255u) / 256u);
     hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, scene->d_camtab,
-                       scene->n_padded, a.cam_pos);
+                       scene->n_padded, a.cam_pos, a.col_delta);
     RT_CHECK(hipGetLastError());
   }
-  bool const tiled = is_tiled(scene->n_padded);
   unsigned long long const my_items = ((unsigned long long)a.n_items + a.slice_count - 1u) / a.slice_count;
-  int const blocks = persistent_blocks(scene->n_padded, my_items);
-  size_t const lds = lds_bytes(scene->n_padded);
+  int const blocks = persistent_blocks(scene, my_items);
+  size_t const lds = lds_bytes(scene);
   if (ev_start)
     RT_CHECK(hipEventRecord(ev_start, stream));
-  if (tiled)
-    hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, a);
-  else
-    hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, a);
+  with_trace_kernel(scene, [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, stream, a);
+    return hipSuccess;
+  });
   RT_CHECK(hipGetLastError());
   if (ev_stop)
     RT_CHECK(hipEventRecord(ev_stop, stream));
@@ -624,6 +742,7 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   s->n_padded = static_cast<uint32_t>(fs.spheres.size());
   s->n_materials = material_count;
   s->n_lights = light_count;
+  s->forward_ok = forward_accumulation_ok(materials, material_count) && std::getenv("RT_HIP_FORCE_STACK") == nullptr;
   auto upload = [](void ** dst, const void * src, size_t bytes) -> hipError_t {
     // Never a zero-byte allocation: keep the pointer valid for empty arrays.
     hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));

@@ -6,6 +6,7 @@
 #include "rt_core.h"
 #include "rt_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -38,6 +39,45 @@ inline void prepare_frame(const rt_hip_camera & cam, const rt_hip_trace_params &
   a.max_depth = (p.max_depth == 0u || p.max_depth > RT_MAX_DEPTH) ? RT_MAX_DEPTH : p.max_depth;
   a.slice_count = p.slice_count ? p.slice_count : 1u;
   a.slice_index = p.slice_index % a.slice_count;
+}
+
+// Bound on |D_s - D_c| between the direction through the middle of a sub-sample column and the direction of
+// any of its samples: the unnormalised directions differ by at most |up| * cell_y / 2 and are at least
+// znear * |dir| long; the slack covers the approximate normalisation of D_c and float rounding.
+inline float column_delta(const TraceArgs & a)
+{
+  double const up = std::sqrt((double)a.cam_up.x * a.cam_up.x + (double)a.cam_up.y * a.cam_up.y +
+                              (double)a.cam_up.z * a.cam_up.z);
+  double const dir = std::sqrt((double)a.cam_dir.x * a.cam_dir.x + (double)a.cam_dir.y * a.cam_dir.y +
+                               (double)a.cam_dir.z * a.cam_dir.z);
+  double const d = up * std::fabs((double)a.cell_y) * 0.5 / (std::fabs((double)a.znear) * dir);
+  return (float)(d * 1.001 + 1e-6);
+}
+
+// True when the early exit of the reverse accumulation loop (demos/demo_frame_cpu.cpp:70-71, |rest| < kEps)
+// can never trigger with these materials, so a path's colour is prod(l_i) * prod(e_k ^ k) / 2.  rest is a
+// product of at most RT_MAX_DEPTH emissivities: 0.7 for Matte, 1 for Glass, 0.9 (1 - roughness) for Metal
+// (ray_tracing/default_materials.cpp:18,30,66); a Metal whose value is below kEps always ends the path instead
+// (demos/demo_frame_cpu.cpp:39-45) and never enters a product.
+inline bool forward_accumulation_ok(const rt_hip_material * mats, uint32_t m)
+{
+  double lo = 1.0;
+  for (uint32_t i = 0; i < m; ++i)
+  {
+    float e = 1.0f;
+    if (mats[i].type == RT_HIP_MATERIAL_MATTE)
+      e = 0.7f;
+    else if (mats[i].type == RT_HIP_MATERIAL_METAL)
+    {
+      e = 0.9f * (1.0f - mats[i].roughness);
+      if (std::fabs(e) < RT_EPS)
+        continue;
+    }
+    if (!(e > 0.0f))
+      return false;
+    lo = std::min(lo, (double)e);
+  }
+  return std::pow(lo, (double)RT_MAX_DEPTH) >= 2.0 * (double)RT_EPS;
 }
 
 // Scene records in the layout the kernel reads.

@@ -20,15 +20,34 @@ struct HostEnv
   bool any(bool p) { return p; }
   int count(bool p) { return p ? 1 : 0; }
   bool any_wave(bool p) { return p; }
-  uint32_t fetch_item(bool need)
+  void fetch_item(bool need, rtc::ItemInfo & info)
   {
+    info.item = rtc::RT_INVALID;
+    info.prepared = false;
+    info.filter_tests = 0;
     if (!need)
-      return rtc::RT_INVALID;
+      return;
     unsigned long long const q = A.slice_index + (unsigned long long)A.slice_count * next++;
-    return q < total ? (uint32_t)q : rtc::RT_INVALID;
+    if (q >= total)
+      return;
+    info.item = (uint32_t)q;
+    if (A.column_masks != 0u)
+    {
+      rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, info.item);
+      info.prepared = true;
+      info.sdx = e.sdx;
+      info.dyp = e.dyp;
+      info.cm0 = e.cm0;
+      info.cm1 = e.cm1;
+      info.pixel = e.pixel;
+      info.sx = e.sx;
+      info.filter_tests = A.n_spheres;
+    }
   }
   rtc::f4 sphere(int i) const { return A.spheres[i]; }
   uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+  rtc::f4 material(uint32_t m, uint32_t k) const { return A.materials[2u * m + k]; }
+  rtc::f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
   uint32_t tiles() const { return (A.n_padded + tile_size - 1) / tile_size; }
   uint32_t tile_base(uint32_t k) const { return k * tile_size; }
   uint32_t load_tile(uint32_t k, bool primary)
@@ -42,23 +61,46 @@ struct HostEnv
 };
 }  // namespace
 
-// tile_size: records per staged tile, a multiple of 4 (exercises the multi-tile path when smaller than the scene).
+// tile_size: records per staged tile (exercises the multi-tile path when smaller than the scene).
+// mode: bit 0 = column masks (scenes of at most 64 spheres, one tile), bit 1 = forward accumulation.
+extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * material_index, uint32_t n,
+                               const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
+                               const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
+                               uint32_t mode, float * rgb, unsigned long long * stats6);
+
+extern "C" int emu_forward_ok(const rt_hip_material * mats, uint32_t m)
+{
+  return rtc::forward_accumulation_ok(mats, m) ? 1 : 0;
+}
+
 extern "C" int emu_render(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                           const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                           const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
                           float * rgb, unsigned long long * stats6)
+{
+  return emu_render_mode(centers_radii, material_index, n, mats, m, lights, l, cam, p, tile_size, 0u, rgb, stats6);
+}
+
+extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * material_index, uint32_t n,
+                          const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
+                               const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
+                               uint32_t mode, float * rgb, unsigned long long * stats6)
 {
   rtc::FlatScene fs;
   rtc::flatten_scene(centers_radii, material_index, n, mats, m, lights, l, fs);
   rtc::TraceArgs a{};
   rtc::prepare_frame(*cam, *p, a);
   uint32_t const padded = static_cast<uint32_t>(fs.filter.size());
+  bool const column_masks = (mode & 1u) != 0u && padded > 0 && padded <= 64;
+  a.column_masks = column_masks ? 1u : 0u;
+  a.col_delta = column_masks ? rtc::column_delta(a) : 0.0f;
   std::vector<rtc::f4> camtab(padded);
   for (uint32_t i = 0; i < padded; ++i)
   {
     float const dx = fs.filter[i].x - a.cam_pos.x, dy = fs.filter[i].y - a.cam_pos.y,
                 dz = fs.filter[i].z - a.cam_pos.z;
-    camtab[i] = rtc::mk4(dx, dy, dz, rtc::filter_bound(dx, dy, dz, fs.filter[i].w));
+    float const len = std::sqrt(dx * dx + dy * dy + dz * dz) * 1.000001f;
+    camtab[i] = rtc::mk4(dx, dy, dz, rtc::filter_bound(dx, dy, dz, fs.filter[i].w) - len * a.col_delta);
   }
   a.spheres = fs.spheres.data();
   a.filter = fs.filter.data();
@@ -80,8 +122,11 @@ extern "C" int emu_render(const float * centers_radii, const uint32_t * material
 
   std::vector<rtc::f4> stack(rtc::RT_MAX_DEPTH);
   rtc::LaneCounters cnt{};
-  HostEnv env{a, a.n_items, tile_size ? tile_size : (padded ? padded : 4u)};
-  rtc::trace_loop(a, env, stack.data(), 1u, cnt);
+  HostEnv env{a, a.n_items, (tile_size && !column_masks) ? tile_size : (padded ? padded : 4u)};
+  if ((mode & 2u) != 0u)
+    rtc::trace_loop<true>(a, env, stack.data(), 1u, cnt);
+  else
+    rtc::trace_loop<false>(a, env, stack.data(), 1u, cnt);
 
   // accumulate (owned columns in increasing sx) + resolve, as colsum_kernel and resolve_kernel do
   float const inv = 1.0f / static_cast<float>(s_row * s_row);

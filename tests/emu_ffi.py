@@ -24,18 +24,28 @@ def load():
         lib.emu_render.restype = C.c_int
         lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                    C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.emu_render_mode.restype = C.c_int
+        lib.emu_render_mode.argtypes = lib.emu_render.argtypes[:10] + [C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.emu_forward_ok.restype = C.c_int
+        lib.emu_forward_ok.argtypes = [C.c_void_p, C.c_uint32]
         _lib = lib
     return _lib
 
 
-def render(scene, p, tile_size=0):
+def forward_ok(scene):
+    """The host's decision whether a scene's paths may be accumulated forward."""
+    return bool(load().emu_forward_ok(C.cast(scene.materials, C.c_void_p), scene.material_count))
+
+
+def render(scene, p, tile_size=0, column_masks=False, forward=False):
     lib = load()
     rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
     stats = np.zeros(6, dtype=np.uint64)
-    rc = lib.emu_render(scene.centers_radii.ctypes.data, scene.material_index.ctypes.data, scene.sphere_count,
-                        C.cast(scene.materials, C.c_void_p), scene.material_count,
-                        C.cast(scene.lights, C.c_void_p), scene.light_count,
-                        C.byref(scene.camera), C.byref(p), tile_size, rgb.ctypes.data, stats.ctypes.data)
+    mode = (1 if column_masks else 0) | (2 if forward else 0)
+    rc = lib.emu_render_mode(scene.centers_radii.ctypes.data, scene.material_index.ctypes.data, scene.sphere_count,
+                             C.cast(scene.materials, C.c_void_p), scene.material_count,
+                             C.cast(scene.lights, C.c_void_p), scene.light_count,
+                             C.byref(scene.camera), C.byref(p), tile_size, mode, rgb.ctypes.data, stats.ctypes.data)
     assert rc == 0
     keys = ["samples", "ray_queries", "hit_queries", "shaded_bounces", "sphere_tests", "exact_tests"]
     return rgb, dict(zip(keys, (int(x) for x in stats)))

@@ -25,6 +25,45 @@ def test_deterministic_frames_match(oracle, ffi, scenes, demo, spheres, depth):
         assert es[key] == getattr(rs, key), key
 
 
+@pytest.mark.parametrize("demo", [1, 2])
+@pytest.mark.parametrize("column_masks,forward", [(True, False), (False, True), (True, True)])
+def test_column_masks_and_forward_accumulation(oracle, ffi, scenes, demo, column_masks, forward):
+    """The two shortcuts small scenes take: one primary filter pass per sub-sample column, and path colours
+    accumulated as running products instead of the reverse loop over a stack."""
+    scene = scenes(demo)
+    assert emu_ffi.forward_ok(scene)
+    for s, flags in ((2, ffi.FLAG_DETERMINISTIC), (5, ffi.FLAG_DETERMINISTIC), (3, 0)):
+        p = ffi.params(64, 48, s, flags=flags, seed=5)
+        ref, rs = oracle.render(scene, p, 4)
+        out, es = emu_ffi.render(scene, p, column_masks=column_masks, forward=forward)
+        if flags:
+            assert rel_err(ref, out).max() < 2e-6
+            for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces"):
+                assert es[key] == getattr(rs, key), key
+        else:
+            assert np.abs(ref - out).mean() < 1e-5
+        if column_masks:  # one filter pass per column instead of one per sample
+            assert es["sphere_tests"] < rs.sphere_tests
+
+
+def test_column_masks_match_per_sample_filtering_bit_for_bit(ffi, scenes):
+    scene = scenes(1)
+    p = ffi.params(96, 72, 4, seed=3)
+    a, sa = emu_ffi.render(scene, p)
+    b, sb = emu_ffi.render(scene, p, column_masks=True)
+    np.testing.assert_array_equal(a, b)
+    assert sa["hit_queries"] == sb["hit_queries"] and sa["ray_queries"] == sb["ray_queries"]
+
+
+def test_forward_accumulation_is_refused_when_the_energy_break_can_trigger(ffi):
+    rough = ffi.Scene.build([(0.0, 0.0, 2.0, 1.0, 0)], [(1, (0.9, 0.9, 0.9), 0.95, 0.1)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
+    assert not emu_ffi.forward_ok(rough)
+    negative = ffi.Scene.build([(0.0, 0.0, 2.0, 1.0, 0)], [(1, (0.9, 0.9, 0.9), 1.5, 0.1)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
+    assert not emu_ffi.forward_ok(negative)
+    absorbing = ffi.Scene.build([(0.0, 0.0, 2.0, 1.0, 0)], [(1, (0.9, 0.9, 0.9), 1.0, 0.1)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
+    assert emu_ffi.forward_ok(absorbing)  # emissivity 0: such a hit always ends the path
+
+
 def test_filter_is_conservative_on_the_demo_scenes(oracle, ffi, scenes):
     """Same hit counts as the brute-force oracle: the filter never drops a ray the exact test accepts."""
     for demo in (1, 2):
