@@ -121,23 +121,21 @@ static void draw_scatter(const orc_params * params, uint32_t pixel, uint32_t sam
     u[i] = orc_uniform(w[i]);
 }
 
-/* Blocks 1 + 2*light and 2 + 2*light of a bounce: their eight words are cut into sixteen 16-bit halves
- * h[0..15] (low half first); shadow sample j takes h[3j], h[3j+1], h[3j+2] as uniforms h / 65536. */
+/* Block 1 + light of a bounce: its sixteen bytes b[0..15] (word 0 low byte first); shadow sample j takes
+ * b[3j], b[3j+1], b[3j+2] as uniforms (b + 0.5) / 256 (the middle of each of the 256 cells). */
 static void draw_shadow_jitter(const orc_params * params, uint32_t pixel, uint32_t sample, uint32_t bounce,
                                uint32_t light, v3 jitter[ORC_LIGHT_SAMPLES])
 {
-  uint32_t w[8];
-  philox_block(params, pixel, sample, bounce, 1u + 2u * light, w);
-  philox_block(params, pixel, sample, bounce, 2u + 2u * light, w + 4);
+  uint32_t w[4];
+  philox_block(params, pixel, sample, bounce, 1u + light, w);
   for (uint32_t j = 0; j < ORC_LIGHT_SAMPLES; ++j)
   {
     float u[3], b[3];
     for (uint32_t q = 0; q < 3; ++q)
     {
       uint32_t const h = 3u * j + q;
-      uint32_t const word = w[h >> 1];
-      uint32_t const half = (h & 1u) ? (word >> 16) : (word & 0xFFFFu);
-      u[q] = (float)half * (1.0f / 65536.0f);
+      uint32_t const byte = (w[h >> 2] >> (8u * (h & 3u))) & 0xFFu;
+      u[q] = (float)byte * (1.0f / 256.0f) + (0.5f / 256.0f);
     }
     orc_ball(0.25f, u[0], u[1], u[2], b);
     jitter[j] = ld(b);

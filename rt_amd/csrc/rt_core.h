@@ -52,6 +52,7 @@ constexpr float RT_EPS = 1e-5f;        // ray_tracing/types.hpp:9
 constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
 constexpr uint32_t RT_PAD = 1;         // sphere arrays are padded to a multiple of this with never-hit entries
+constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
 constexpr uint32_t RT_UNROLL = 4;      // spheres per trip of the filter loops' main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
@@ -87,11 +88,28 @@ RT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 RT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 RT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Three consecutive floats in one 12-byte store (4-byte aligned).
+RT_HD void store3(float * p, f3 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
+  f3v t;
+  t.x = v.x;
+  t.y = v.y;
+  t.z = v.z;
+  *reinterpret_cast<f3v *>(p) = t;
+#else
+  p[0] = v.x;
+  p[1] = v.y;
+  p[2] = v.z;
+#endif
+}
 
 // ---- approximate hardware math (one instruction each on gfx950, about 1 ulp); libm on the host ----
 #if defined(__HIPCC__)
 RT_FN float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 RT_FN float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+RT_FN float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 RT_FN float hw_sin_rev(float r) { return __builtin_amdgcn_sinf(r); }  // sin(2*pi*r)
 RT_FN float hw_cos_rev(float r) { return __builtin_amdgcn_cosf(r); }
 RT_FN float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -106,6 +124,7 @@ RT_FN uint32_t push_sign(uint32_t mask, float x) { return __builtin_amdgcn_align
 #else
 RT_FN float hw_sqrt(float x) { return sqrtf(x); }
 RT_FN float hw_rsq(float x) { return 1.0f / sqrtf(x); }
+RT_FN float hw_rcp(float x) { return 1.0f / x; }
 RT_FN float hw_sin_rev(float r) { return sinf(6.28318530717958647692f * r); }
 RT_FN float hw_cos_rev(float r) { return cosf(6.28318530717958647692f * r); }
 RT_FN float hw_exp2(float x) { return exp2f(x); }
@@ -162,7 +181,7 @@ RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 }
 
 RT_FN float uniform24(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
-RT_FN float uniform16(uint32_t half) { return (float)half * (1.0f / 65536.0f); }
+RT_FN float uniform8(uint32_t byte) { return (float)byte * (1.0f / 256.0f) + (0.5f / 256.0f); }
 
 // Uniform point in a ball of radius R from three uniforms: direction uniform on the sphere, radius
 // R * u^(1/3).  Same law as glm::ballRand with a fixed draw count, so no lane waits on a rejection loop.
@@ -182,7 +201,8 @@ struct TraceArgs
   const f4 * filter;           // n_padded x (cx, cy, cz, r*r widened by the filter margin)
   const f4 * camtab;           // n_padded x (centre - camera, filter bound): the primary-ray filter
   const uint32_t * sphere_mat; // n_spheres
-  const f4 * materials;        // n_materials x 2: (albedo rgb, roughness), (refraction, type bits, 0, 0)
+  const f4 * materials;        // n_materials x RT_MAT_RECORDS: (albedo rgb, roughness), (refraction, type bits,
+                               // f0^2, 1 / refraction), (r^2, 4 r^2, metal emissivity, 0) with r = max(roughness, 0.03)
   const f4 * lights;           // n_lights x 2: (direction xyz, 0), (colour rgb, 0)
   uint32_t n_spheres, n_padded, n_materials, n_lights;
   uint32_t tile_size;          // filter records staged per tile when the scene is not resident (multiple of RT_PAD)
@@ -198,7 +218,7 @@ struct TraceArgs
   uint32_t column_masks;      // 0: filter every primary ray on its own (col_delta is 0 then)
   float col_delta;
   // outputs
-  float * partial;            // 3 planes of n_items column sums: partial[c * n_items + pixel * s_row + sx]
+  float * partial;            // n_items column sums, RGB interleaved: partial[3 * (pixel * s_row + sx) + c]
   uint32_t n_items;           // width * height * s_row
   uint32_t * queue_counter;   // next work item of this slice to hand out
   const uint32_t * cancel;    // non-zero: stop handing out work (host-visible memory, read on refills only)
@@ -227,6 +247,9 @@ struct LaneCounters
     (cnt).region[k] += now_ - (cnt).last_tick;                              \
     (cnt).last_tick = now_;                                                 \
   } while (0)
+#elif defined(RT_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+// Listing aid: leaves "; MARK k" comments in the assembly so that instructions can be counted per region.
+#define RT_REGION(cnt, k) asm volatile("; MARK " #k)
 #else
 #define RT_REGION(cnt, k) ((void)0)
 #endif
@@ -360,22 +383,30 @@ RT_FN ColumnEntry prepare_column(const TraceArgs & A, const f4 * camtab, uint32_
   return e;
 }
 
-// Material::Scatter for the three materials, ray_tracing/default_materials.cpp:11-67.
-RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n, f3 ball, float xi,
-                   f3 & out_dir, float & out_e)
+// The material constants a hit needs, from the three records of its material.
+struct MaterialView
+{
+  uint32_t type;
+  float roughness, refraction;
+  float f2;              // ((1 - refraction) / (1 + refraction))^2
+  float inv_refraction;  // 1 / refraction
+  float r2, four_r2;     // max(roughness, 0.03)^2 and four times it
+  float e_metal;         // 0.9 (1 - roughness)
+};
+
+// Material::Scatter for the three materials, ray_tracing/default_materials.cpp:11-67.  Matte and Metal share
+// one normalisation (of n + ball, or of reflect + ball * roughness).
+RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & out_dir, float & out_e)
 {
   float const dn = dot3(n, rd);
   f3 const refl = rd - n * dn * 2.0f;  // glm::reflect(I, N) = I - N * dot(N, I) * 2
-  if (type == RT_MATTE)
+  if (m.type != RT_GLASS)
   {
-    out_dir = normalize3(n + ball);
-    out_e = 0.7f;
-  }
-  else if (type == RT_METAL)
-  {
-    f3 const r = normalize3(refl + ball * roughness);
+    bool const matte = m.type == RT_MATTE;
+    f3 const v = matte ? n + ball : refl + ball * m.roughness;
+    f3 const r = normalize3(v);
     out_dir = r;
-    out_e = (dot3(n, r) <= 0.0f) ? 0.0f : 0.9f * (1.0f - roughness);
+    out_e = matte ? 0.7f : ((dot3(n, r) <= 0.0f) ? 0.0f : m.e_metal);
   }
   else
   {
@@ -385,13 +416,13 @@ RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n
     if (vdn > 0.0f)
     {
       outward = -n;
-      eta = refraction;
+      eta = m.refraction;
       vdn *= eta;
     }
     else
     {
       outward = n;
-      eta = 1.0f / refraction;
+      eta = m.inv_refraction;
       vdn = -vdn;
     }
     // glm::refract(I, N, eta)
@@ -402,32 +433,27 @@ RT_FN void scatter(uint32_t type, float roughness, float refraction, f3 rd, f3 n
       refr = rd * eta - outward * (eta * d + sqrtf(k));
     float ref = 1.0f;
     if (dot3(refr, refr) > RT_EPS)
-    {
-      float const f0 = (1.0f - refraction) / (1.0f + refraction);
-      float const f2 = f0 * f0;
-      ref = f2 + (1.0f - f2) * pow5(1.0f - vdn);
-    }
+      ref = m.f2 + (1.0f - m.f2) * pow5(1.0f - vdn);
     out_dir = (xi < ref) ? refl : refr;
     out_e = 1.0f;
   }
 }
 
-// DirectionalLight::GetSpecular, ray_tracing/directional_light.cpp:37-60.
-RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, float m_roughness, float m_refraction, f3 rd, f3 n)
+// DirectionalLight::GetSpecular, ray_tracing/directional_light.cpp:37-60.  The half vector and the cosines are
+// computed exactly (the Beckmann exponent multiplies their rounding by up to 1 / 0.03^2); the three quotients
+// and the exponential behind them only scale the result and use the hardware reciprocal and exp2 (~1e-6).
+RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, const MaterialView & m, f3 rd, f3 n)
 {
   float const vdn = clampf(dot3(-rd, n), 0.0f, 1.0f);
   float const ndl = clampf(dot3(n, -ldir), 0.0f, 1.0f);
   f3 const h = -normalize3(ldir + rd);
   float const ndh = clampf(dot3(n, h), RT_EPS, 1.0f);
   float const vdh = clampf(dot3(-rd, h), 0.0f, 1.0f);
-  float const g = (fabsf(vdh) >= RT_EPS) ? minf(1.0f, 2.0f * ndh * minf(vdn, ndl) / vdh) : 1.0f;
+  float const g = (fabsf(vdh) >= RT_EPS) ? minf(1.0f, 2.0f * ndh * minf(vdn, ndl) * hw_rcp(vdh)) : 1.0f;
   float const ndh2 = ndh * ndh;
-  float const roughness = maxf(m_roughness, 0.03f);
-  float const r2 = roughness * roughness;
-  float const dm = expf((ndh2 - 1.0f) / (r2 * ndh2)) / (4.0f * r2 * ndh2 * ndh2);
-  float const f0 = (1.0f - m_refraction) / (1.0f + m_refraction);
-  float const f2 = f0 * f0;
-  float const f = f2 + (1.0f - f2) * pow5(1.0f - vdn);
+  float const q = (ndh2 - 1.0f) * hw_rcp(m.r2 * ndh2);
+  float const dm = hw_exp2(q * 1.44269504088896340736f) * hw_rcp(m.four_r2 * ndh2 * ndh2);
+  float const f = m.f2 + (1.0f - m.f2) * pow5(1.0f - vdn);
   float const spec = clampf(g * dm * f, 0.0f, 1.0f);
   return mix3(lcol, albedo, 0.5f) * spec;
 }
@@ -749,12 +775,10 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     {
       cnt.rounds += 1;
       bool need = L.alive && !L.has_hit && !L.shading;
-      // Column complete: one plain store per plane; every item is written by exactly one lane.
+      // Column complete: one 12-byte store; every item is written by exactly one lane.
       if (need && !L.need_item && L.sy >= A.s_row)
       {
-        A.partial[L.item] = L.sum.x;
-        A.partial[A.n_items + L.item] = L.sum.y;
-        A.partial[2u * A.n_items + L.item] = L.sum.z;
+        store3(A.partial + 3u * (size_t)L.item, L.sum);
         L.need_item = true;
       }
       bool const ask = need && L.need_item;
@@ -858,10 +882,18 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       uint32_t const mi = env.sphere_material(L.hidx);
       f4 const m0 = env.material(mi, 0u);
       f4 const m1 = env.material(mi, 1u);
-      uint32_t const mtype = f2u(m1.y);
+      f4 const m2 = env.material(mi, 2u);
+      MaterialView mv;
+      mv.type = f2u(m1.y);
+      mv.roughness = m0.w;
+      mv.refraction = m1.x;
+      mv.f2 = m1.z;
+      mv.inv_refraction = m1.w;
+      mv.r2 = m2.x;
+      mv.four_r2 = m2.y;
+      mv.e_metal = m2.z;
       L.m_albedo = mk3(m0.x, m0.y, m0.z);
-      float const m_rough = m0.w;
-      L.m_refraction = m1.x;
+      L.m_refraction = mv.refraction;
 
       f3 ball = mk3(0.0f, 0.0f, 0.0f);
       float xi = 0.5f;
@@ -871,7 +903,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         ball = ball3(1.0f, uniform24(rw.x), uniform24(rw.y), uniform24(rw.z));
         xi = uniform24(rw.w);
       }
-      scatter(mtype, m_rough, L.m_refraction, L.hd, L.hn, ball, xi, L.sdir, L.e);
+      scatter(mv, L.hd, L.hn, ball, xi, L.sdir, L.e);
       L.has_hit = false;
       if (fabsf(L.e) < RT_EPS)
       {
@@ -887,8 +919,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         {
           f4 const l0 = env.light(li, 0u);
           f4 const l1 = env.light(li, 1u);
-          L.spec = L.spec + specular(mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), L.m_albedo, m_rough,
-                                     L.m_refraction, L.hd, L.hn);
+          L.spec = L.spec + specular(mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), L.m_albedo, mv, L.hd, L.hn);
         }
         L.diffuse = mk3(0.0f, 0.0f, 0.0f);
         L.li = 0;
@@ -913,10 +944,9 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           jit[j] = mk3(0.0f, 0.0f, 0.0f);
         if (!deterministic)
         {
-          // 15 uniforms of 16 bits from two Philox blocks: half-words h[0..15], ball j takes h[3j..3j+2].
-          u4 const p0 = philox4x32_10(L.depth, 1u + 2u * L.li, L.sample, 0u, L.pixel, A.seed);
-          u4 const p1 = philox4x32_10(L.depth, 2u + 2u * L.li, L.sample, 0u, L.pixel, A.seed);
-          uint32_t const wd[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+          // 15 uniforms of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
+          u4 const p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
+          uint32_t const wd[4] = {p0.x, p0.y, p0.z, p0.w};
 #pragma unroll
           for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
           {
@@ -925,8 +955,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             for (int q = 0; q < 3; ++q)
             {
               int const h = 3 * j + q;
-              uint32_t const word = wd[h >> 1];
-              u[q] = uniform16((h & 1) ? (word >> 16) : (word & 0xFFFFu));
+              u[q] = uniform8((wd[h >> 2] >> (8 * (h & 3))) & 0xFFu);
             }
             jit[j] = ball3(0.25f, u[0], u[1], u[2]);
           }

@@ -15,7 +15,7 @@
 //
 //   camtab_kernel        per-frame table of the primary-ray filter, one entry per sphere.
 //
-// LDS per block: the resident scene (48 B per sphere, 32 B per material and light) and 8 KB of prepared
+// LDS per block: the resident scene (48 B per sphere and material, 32 B per light) and 8 KB of prepared
 // columns, or one 16 KB staging tile for scenes above kResidentSpheres spheres.
 #include "rt_core.h"
 #include "rt_hip.h"
@@ -125,7 +125,7 @@ struct WaveEnv
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[2u * m + k]; }
+  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[RT_MAT_RECORDS * m + k]; }
   __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return lights[2u * l + k]; }
   __device__ __forceinline__ uint32_t tiles() const { return 1u; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
@@ -210,7 +210,7 @@ struct BlockEnv
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[2u * m + k]; }
+  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[RT_MAT_RECORDS * m + k]; }
   __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
   __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + A.tile_size - 1u) / A.tile_size; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * A.tile_size; }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
     f4 * cam = sph + A.n_padded;
     f4 * exact = cam + A.n_padded;
     f4 * mats = exact + A.n_padded;
-    f4 * lights = mats + 2u * A.n_materials;
+    f4 * lights = mats + RT_MAT_RECORDS * A.n_materials;
     ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(lights + 2u * A.n_lights);
     for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
     {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
       cam[i] = A.camtab[i];
       exact[i] = A.spheres[i];
     }
-    for (uint32_t i = threadIdx.x; i < 2u * A.n_materials; i += kBlock)
+    for (uint32_t i = threadIdx.x; i < RT_MAT_RECORDS * A.n_materials; i += kBlock)
       mats[i] = A.materials[i];
     for (uint32_t i = threadIdx.x; i < 2u * A.n_lights; i += kBlock)
       lights[i] = A.lights[i];
@@ -326,15 +326,15 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
   camtab[i] = e;
 }
 
-// The accumulate pass: per pixel and plane, the column sums this slice owns are added in increasing sx
-// (the order Frame::ForEachRayImpl adds its outer loop, ray_tracing/frame.cpp:56).  partial: 3 planes of
-// n * s_row floats; planes: 3 planes of n floats.  One lane per pixel; a pixel's columns are contiguous.
+// The accumulate pass: per pixel, the column sums this slice owns are added in increasing sx (the order
+// Frame::ForEachRayImpl adds its outer loop, ray_tracing/frame.cpp:56).  partial: n * s_row interleaved RGB
+// column sums (a pixel's columns are contiguous: 12 * s_row bytes); planes: 3 planes of n floats.  One lane
+// per pixel.
 __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ partial, float * __restrict__ planes,
                                                      uint32_t n, uint32_t s_row, uint32_t slice_index,
                                                      uint32_t slice_count)
 {
   uint32_t const stride = gridDim.x * blockDim.x;
-  size_t const n_items = (size_t)n * s_row;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
   {
     size_t const first = (size_t)p * s_row;
@@ -343,9 +343,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ 
     float r = 0.0f, g = 0.0f, b = 0.0f;
     for (uint32_t sx = sx0; sx < s_row; sx += slice_count)
     {
-      r += partial[first + sx];
-      g += partial[n_items + first + sx];
-      b += partial[2u * n_items + first + sx];
+      const float * c = partial + 3u * (first + sx);
+      r += c[0];
+      g += c[1];
+      b += c[2];
     }
     planes[p] = r;
     planes[n + p] = g;
@@ -436,7 +437,7 @@ struct rt_hip_scene
 struct rt_hip_job
 {
   rt_hip_trace_params params;
-  float * d_partial = nullptr;  // 3 * width * height * samples_in_row column sums
+  float * d_partial = nullptr;  // width * height * samples_in_row column sums, RGB interleaved
   float * d_planes = nullptr;
   float * d_rgb = nullptr;
   unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
@@ -478,7 +479,7 @@ size_t lds_bytes(const rt_hip_scene * sc)
   if (is_tiled(sc))
     bytes += sizeof(f4) * (size_t)kTileSpheres;
   else
-    bytes += sizeof(f4) * (size_t)(3u * sc->n_padded + 2u * sc->n_materials + 2u * sc->n_lights) +
+    bytes += sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + 2u * sc->n_lights) +
              sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
   return std::max<size_t>(bytes, 16u);
 }

@@ -86,7 +86,7 @@ struct FlatScene
   std::vector<f4> spheres;           // (cx, cy, cz, r*r), padded to a multiple of RT_PAD
   std::vector<f4> filter;            // (cx, cy, cz, r*r widened by the filter margin), padded likewise
   std::vector<uint32_t> sphere_mat;  // material index per sphere
-  std::vector<f4> materials;         // 2 per material
+  std::vector<f4> materials;         // RT_MAT_RECORDS per material
   std::vector<f4> lights;            // 2 per light
 };
 
@@ -117,14 +117,24 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
     double const widened = static_cast<double>(r2) * (1.0 + RT_FILTER_MARGIN);
     out.filter[i] = mk4(s[0], s[1], s[2], std::nextafter(static_cast<float>(widened), INFINITY));
   }
-  out.materials.resize(2u * m);
+  // Per-material constants of Scatter and GetSpecular, computed here once with the float operations the
+  // reference uses per hit (ray_tracing/default_materials.cpp:30,50,61-62; directional_light.cpp:49-56).
+  out.materials.resize((size_t)RT_MAT_RECORDS * m);
   for (uint32_t i = 0; i < m; ++i)
   {
     float type_bits;
     uint32_t const t = mats[i].type;
     std::memcpy(&type_bits, &t, 4);
-    out.materials[2u * i] = mk4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].roughness);
-    out.materials[2u * i + 1u] = mk4(mats[i].refraction, type_bits, 0.0f, 0.0f);
+    float const refraction = mats[i].refraction;
+    float const f0 = (1.0f - refraction) / (1.0f + refraction);
+    float const f2 = f0 * f0;
+    float const inv_refraction = 1.0f / refraction;
+    float const rough = (mats[i].roughness < 0.03f) ? 0.03f : mats[i].roughness;  // std::max(roughness, 0.03f)
+    float const r2 = rough * rough;
+    float const e_metal = 0.9f * (1.0f - mats[i].roughness);
+    out.materials[RT_MAT_RECORDS * i] = mk4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].roughness);
+    out.materials[RT_MAT_RECORDS * i + 1u] = mk4(refraction, type_bits, f2, inv_refraction);
+    out.materials[RT_MAT_RECORDS * i + 2u] = mk4(r2, 4.0f * r2, e_metal, 0.0f);
   }
   out.lights.resize(2u * l);
   for (uint32_t i = 0; i < l; ++i)

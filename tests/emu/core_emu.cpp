@@ -46,7 +46,7 @@ struct HostEnv
   }
   rtc::f4 sphere(int i) const { return A.spheres[i]; }
   uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
-  rtc::f4 material(uint32_t m, uint32_t k) const { return A.materials[2u * m + k]; }
+  rtc::f4 material(uint32_t m, uint32_t k) const { return A.materials[rtc::RT_MAT_RECORDS * m + k]; }
   rtc::f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
   uint32_t tiles() const { return (A.n_padded + tile_size - 1) / tile_size; }
   uint32_t tile_base(uint32_t k) const { return k * tile_size; }
@@ -136,7 +136,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
       float sum = 0.0f;
       for (uint32_t sx = 0; sx < s_row; ++sx)
         if (((unsigned long long)i * s_row + sx) % a.slice_count == a.slice_index)
-          sum += partial[(size_t)c * a.n_items + (size_t)i * s_row + sx];
+          sum += partial[3u * ((size_t)i * s_row + sx) + c];
       rgb[3u * (size_t)i + c] = sum * inv;
     }
   if (stats6)
