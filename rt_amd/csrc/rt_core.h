@@ -181,10 +181,24 @@ RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 }
 
 RT_FN float uniform24(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
-RT_FN float uniform8(uint32_t byte) { return (float)byte * (1.0f / 256.0f) + (0.5f / 256.0f); }
 
 // Uniform point in a ball of radius R from three uniforms: direction uniform on the sphere, radius
 // R * u^(1/3).  Same law as glm::ballRand with a fixed draw count, so no lane waits on a rejection loop.
+// The shadow-ray jitter draws its three uniforms from 256 cells each, so the functions of them are tabulated
+// (built on the host with the C library, rt_prep.h build_jitter_table): per cell k, u = (k + 0.5) / 256,
+//   [0, 512)     (z, s)      z = 1 - 2u, s = sqrt(1 - z^2)
+//   [512, 1024)  (cos, sin)  of 2 pi u
+//   [1024, 1280) 0.25 cbrt(u)
+constexpr uint32_t RT_JITTER_CELLS = 256;
+constexpr uint32_t RT_JITTER_FLOATS = 5u * RT_JITTER_CELLS;
+RT_FN f3 jitter_ball(const float * tab, uint32_t k1, uint32_t k2, uint32_t k3)
+{
+  float const z = tab[2u * k1], s = tab[2u * k1 + 1u];
+  float const c = tab[2u * RT_JITTER_CELLS + 2u * k2], sn = tab[2u * RT_JITTER_CELLS + 2u * k2 + 1u];
+  float const rad = tab[4u * RT_JITTER_CELLS + k3];
+  return mk3((s * c) * rad, (s * sn) * rad, z * rad);
+}
+
 RT_FN f3 ball3(float radius, float u1, float u2, float u3)
 {
   float const z = 1.0f - 2.0f * u1;
@@ -204,6 +218,7 @@ struct TraceArgs
   const f4 * materials;        // n_materials x RT_MAT_RECORDS: (albedo rgb, roughness), (refraction, type bits,
                                // f0^2, 1 / refraction), (r^2, 4 r^2, metal emissivity, 0) with r = max(roughness, 0.03)
   const f4 * lights;           // n_lights x 2: (direction xyz, 0), (colour rgb, 0)
+  const float * jitter_tab;    // RT_JITTER_FLOATS, see jitter_ball
   uint32_t n_spheres, n_padded, n_materials, n_lights;
   uint32_t tile_size;          // filter records staged per tile when the scene is not resident (multiple of RT_PAD)
   // camera, precomputed on the host exactly as Frame::ForEachRayImpl does (ray_tracing/frame.cpp:33-41)
@@ -605,7 +620,7 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //   fetch_item(need, info)  hands a fresh work item to each lane that asks (info.item == RT_INVALID when the
 //                     slice is used up), prepared or not (see ItemInfo)
 //   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i);  material(m, k) and
-//                     light(l, k): record k (0 or 1) of material m / light l
+//                     light(l, k): record k of material m / light l;  jitter_table()
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
 //                     tile_data(primary)
@@ -944,20 +959,20 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           jit[j] = mk3(0.0f, 0.0f, 0.0f);
         if (!deterministic)
         {
-          // 15 uniforms of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
+          // 15 cells of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
           u4 const p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
           uint32_t const wd[4] = {p0.x, p0.y, p0.z, p0.w};
 #pragma unroll
           for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
           {
-            float u[3];
+            uint32_t k[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q)
             {
               int const h = 3 * j + q;
-              u[q] = uniform8((wd[h >> 2] >> (8 * (h & 3))) & 0xFFu);
+              k[q] = (wd[h >> 2] >> (8 * (h & 3))) & 0xFFu;
             }
-            jit[j] = ball3(0.25f, u[0], u[1], u[2]);
+            jit[j] = jitter_ball(env.jitter_table(), k[0], k[1], k[2]);
           }
         }
 #pragma unroll

@@ -117,6 +117,7 @@ struct WaveEnv
   const f4 * exact;      // LDS: n_padded exact records
   const f4 * mats;       // LDS: 2 * n_materials
   const f4 * lights;     // LDS: 2 * n_lights
+  const float * jitter;  // LDS: RT_JITTER_FLOATS
   ColumnEntry * batch;   // LDS: this wave's kItemBatch prepared columns (column masks only)
   ItemPool pool;
 
@@ -127,6 +128,7 @@ struct WaveEnv
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[RT_MAT_RECORDS * m + k]; }
   __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return lights[2u * l + k]; }
+  __device__ __forceinline__ const float * jitter_table() const { return jitter; }
   __device__ __forceinline__ uint32_t tiles() const { return 1u; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return A.n_padded; }
@@ -196,7 +198,8 @@ struct WaveEnv
 struct BlockEnv
 {
   const TraceArgs & A;
-  f4 * tile;  // LDS: kTileSpheres entries
+  f4 * tile;              // LDS: kTileSpheres entries
+  const float * jitter;   // LDS: RT_JITTER_FLOATS
   ItemPool pool;
 
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
@@ -212,6 +215,7 @@ struct BlockEnv
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[RT_MAT_RECORDS * m + k]; }
   __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
+  __device__ __forceinline__ const float * jitter_table() const { return jitter; }
   __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + A.tile_size - 1u) / A.tile_size; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * A.tile_size; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t k, bool primary) const
@@ -240,7 +244,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 __device__ unsigned long long g_region_ticks[RT_REGION_COUNT];
 #endif
 
-// LDS layout: [path stacks, unless kForward][resident: filter, camera table, exact records, materials, lights,
+// LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
 template <bool kTiled, bool kForward>
 __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel(TraceArgs A)
@@ -252,9 +256,15 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
 #if defined(RT_PROFILE_REGIONS)
   cnt.last_tick = __builtin_amdgcn_s_memtime();
 #endif
+  // both layouts start with the jitter table
+  float * jitter = reinterpret_cast<float *>(sph);
+  for (uint32_t i = threadIdx.x; i < RT_JITTER_FLOATS; i += kBlock)
+    jitter[i] = A.jitter_tab[i];
+  sph += RT_JITTER_FLOATS / 4u;
   if constexpr (kTiled)
   {
-    BlockEnv env{A, sph, ItemPool()};
+    __syncthreads();
+    BlockEnv env{A, sph, jitter, ItemPool()};
     trace_loop<kForward>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
     for (uint32_t i = threadIdx.x; i < 2u * A.n_lights; i += kBlock)
       lights[i] = A.lights[i];
     __syncthreads();
-    WaveEnv env{A, sph, cam, exact, mats, lights, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
+    WaveEnv env{A, sph, cam, exact, mats, lights, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
     trace_loop<kForward>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
 
@@ -417,6 +427,7 @@ struct Library
   float * workspace = nullptr;        // column sums of rt_hip_trace_device calls, grown on demand
   size_t workspace_bytes = 0;
   uint32_t * never_cancel = nullptr;  // a zero word for traces that cannot be cancelled
+  float * jitter_tab = nullptr;       // RT_JITTER_FLOATS, see rt_core.h jitter_ball
 };
 Library g_lib;
 
@@ -475,7 +486,7 @@ bool uses_column_masks(const rt_hip_scene * sc)
 // table, exact records, materials, lights, one prepared-column table per wave) or one staging tile.
 size_t lds_bytes(const rt_hip_scene * sc)
 {
-  size_t bytes = sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock);
+  size_t bytes = (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS;
   if (is_tiled(sc))
     bytes += sizeof(f4) * (size_t)kTileSpheres;
   else
@@ -546,6 +557,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.sphere_mat = scene->d_sphere_mat;
   a.materials = scene->d_materials;
   a.lights = scene->d_lights;
+  a.jitter_tab = g_lib.jitter_tab;
   a.n_spheres = scene->n_spheres;
   a.n_padded = scene->n_padded;
   a.tile_size = tile_size();
@@ -674,6 +686,13 @@ int rt_hip_init(int device)
   {
     RT_CHECK(hipMalloc((void **)&g_lib.never_cancel, 64));
     RT_CHECK(hipMemset(g_lib.never_cancel, 0, 64));
+  }
+  if (g_lib.jitter_tab == nullptr)
+  {
+    std::vector<float> tab(RT_JITTER_FLOATS);
+    build_jitter_table(tab.data());
+    RT_CHECK(hipMalloc((void **)&g_lib.jitter_tab, tab.size() * sizeof(float)));
+    RT_CHECK(hipMemcpy(g_lib.jitter_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   g_lib.ready = true;
   return RT_HIP_OK;

@@ -80,6 +80,24 @@ inline bool forward_accumulation_ok(const rt_hip_material * mats, uint32_t m)
   return std::pow(lo, (double)RT_MAX_DEPTH) >= 2.0 * (double)RT_EPS;
 }
 
+// The table jitter_ball reads: the functions of the uniform-in-ball sampler at the 256 cell centres, with the
+// C library's float functions.
+inline void build_jitter_table(float * tab)
+{
+  for (uint32_t k = 0; k < RT_JITTER_CELLS; ++k)
+  {
+    float const u = (float)k * (1.0f / 256.0f) + (0.5f / 256.0f);
+    float const z = 1.0f - 2.0f * u;
+    float const zz = 1.0f - z * z;
+    float const phi = 6.28318530717958647692f * u;
+    tab[2u * k] = z;
+    tab[2u * k + 1u] = std::sqrt(zz < 0.0f ? 0.0f : zz);
+    tab[2u * RT_JITTER_CELLS + 2u * k] = std::cos(phi);
+    tab[2u * RT_JITTER_CELLS + 2u * k + 1u] = std::sin(phi);
+    tab[4u * RT_JITTER_CELLS + k] = 0.25f * std::cbrt(u);
+  }
+}
+
 // Scene records in the layout the kernel reads.
 struct FlatScene
 {

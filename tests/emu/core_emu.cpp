@@ -48,6 +48,7 @@ struct HostEnv
   uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   rtc::f4 material(uint32_t m, uint32_t k) const { return A.materials[rtc::RT_MAT_RECORDS * m + k]; }
   rtc::f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
+  const float * jitter_table() const { return A.jitter_tab; }
   uint32_t tiles() const { return (A.n_padded + tile_size - 1) / tile_size; }
   uint32_t tile_base(uint32_t k) const { return k * tile_size; }
   uint32_t load_tile(uint32_t k, bool primary)
@@ -102,6 +103,9 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     float const len = std::sqrt(dx * dx + dy * dy + dz * dz) * 1.000001f;
     camtab[i] = rtc::mk4(dx, dy, dz, rtc::filter_bound(dx, dy, dz, fs.filter[i].w) - len * a.col_delta);
   }
+  std::vector<float> jitter(rtc::RT_JITTER_FLOATS);
+  rtc::build_jitter_table(jitter.data());
+  a.jitter_tab = jitter.data();
   a.spheres = fs.spheres.data();
   a.filter = fs.filter.data();
   a.camtab = camtab.data();
