@@ -35,6 +35,17 @@ def algorithmic_flop(stats, n_spheres):
     return 20.0 * n_spheres * stats["ray_queries"] + 30.0 * stats["hit_queries"] + 250.0 * stats["shaded_bounces"]
 
 
+def profiled_traffic(workload_key):
+    """HBM bytes per trace launch from the committed rocprofv3 counter passes (FETCH_SIZE doubled as the gfx950
+    guide prescribes for wide reads, plus WRITE_SIZE), or None when this workload was not profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload_key, {}).get("trace_kernel_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(scene, width, height, samples_in_row):
     """The oracle (a port of the reference's CPU path) on a bounded sample of the workload."""
     from oracle import oracle_ffi  # checker; used here as the reported CPU baseline only
@@ -170,12 +181,14 @@ def main():
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
-                "traffic": None,
+                "traffic": profiled_traffic("demo%d_%dx%d_s%d_g%d" % (args.demo, w, h, s, world)),
                 "kernel": "trace_kernel",
                 "kernel_ms": round(kernel_ms, 3),
                 "flop_per_launch": kernel_flop,
                 "executed_filter_tests": k["sphere_tests"],
                 "executed_exact_tests": k["exact_tests"],
+                "executed_over_algorithmic_tests": round(
+                    k["sphere_tests"] / max(k["ray_queries"] * scene.sphere_count, 1), 4),
                 "lane_utilisation": round(k["shaded_bounces"] / max(k["lane_trips"], 1), 4),
             },
         }

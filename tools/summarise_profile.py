@@ -1,0 +1,61 @@
+"""Turns the raw rocprofv3 output of tools/profile.sh (gpurun_out/prof_<tag>/) into the small files kept under
+profiles/: the kernel-trace statistics, the bench line of the same run, a per-kernel counter summary and the
+HBM traffic per trace launch that bench.py reports as roofline.traffic.
+
+python tools/summarise_profile.py <tag>
+"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+shutil.copy(os.path.join(src, "bench", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+with open(os.path.join(src, "bench_stdout.log")) as f:
+    lines = [l for l in f if l.startswith('{"metric"')]
+with open(os.path.join(dst, tag + "_bench_line.json"), "w") as f:
+    f.write(lines[-1])
+
+totals = {}
+with open(os.path.join(dst, tag + "_pmc_summary.txt"), "w") as out:
+    out.write("rocprofv3 --pmc passes over `python3 tools/render_once.py 1 1920 1080 16` (one 1080p 16x16 pretty_spheres\n"
+              "frame), collected by tools/profile.sh; values summed over the dispatches of each kernel in the run (one\n"
+              "trace launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them (FETCH_SIZE uncorrected).\n\n")
+    for name in ("sq1", "sq2", "fetch", "write"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        with open(os.path.join(src, name, name + "_counter_collection.csv")) as f:
+            for r in csv.DictReader(f):
+                m = re.search(r"(\w+_kernel(<[^>]*>)?|__amd_rocclr_\w+)", r["Kernel_Name"])
+                agg[m.group(1) if m else r["Kernel_Name"][:48]][r["Counter_Name"]] += float(r["Counter_Value"])
+        for kernel, counters in agg.items():
+            if "rocclr" in kernel:
+                continue
+            out.write("[%s] %s\n" % (name, kernel))
+            for c, x in sorted(counters.items()):
+                out.write("    %-28s %.0f\n" % (c, x))
+                if "trace_kernel" in kernel:
+                    totals[c] = x
+
+traffic_path = os.path.join(dst, "traffic.json")
+traffic = {}
+if os.path.exists(traffic_path):
+    with open(traffic_path) as f:
+        traffic = json.load(f)
+traffic["demo1_1920x1080_s16_g1"] = {
+    # gfx950: FETCH_SIZE counts half the bytes of wide reads; WRITE_SIZE is exact for 16-byte stores
+    "trace_kernel_bytes_per_launch": int((2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]) * 1024),
+    "fetch_size_kib": totals["FETCH_SIZE"],
+    "write_size_kib": totals["WRITE_SIZE"],
+    "source": "profiles/%s_pmc_summary.txt" % tag,
+}
+with open(traffic_path, "w") as f:
+    json.dump(traffic, f, indent=1)
+print("profiles/%s_* written; trace kernel: %s" % (tag, {k: totals[k] for k in sorted(totals)}))
