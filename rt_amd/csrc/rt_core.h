@@ -233,7 +233,8 @@ struct TraceArgs
   uint32_t column_masks;      // 0: filter every primary ray on its own (col_delta is 0 then)
   float col_delta;
   // outputs
-  float * partial;            // n_items column sums, RGB interleaved: partial[3 * (pixel * s_row + sx) + c]
+  float * partial;            // this slice's column sums, RGB interleaved, in slice order: item slice_index +
+                              // slice_count * k is entry k (partial[3 * k + c])
   uint32_t n_items;           // width * height * s_row
   uint32_t * queue_counter;   // next work item of this slice to hand out
   const uint32_t * cancel;    // non-zero: stop handing out work (host-visible memory, read on refills only)
@@ -305,6 +306,7 @@ struct Lane
 {
   // work item being accumulated: sub-sample column sx of one pixel (its s_row samples sy = 0..s_row-1)
   uint32_t item;    // pixel * s_row + sx
+  uint32_t slot;    // position of the item in this slice (where its column sum goes)
   uint32_t pixel;
   uint32_t sx;
   uint32_t sy;      // next sample of the column (>= s_row: none left)
@@ -357,6 +359,7 @@ RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
 struct ItemInfo
 {
   uint32_t item;          // RT_INVALID: the slice is used up
+  uint32_t slot;          // position of the item in its slice: item = slice_index + slice_count * slot
   bool prepared;
   float sdx, dyp;
   uint32_t cm0, cm1, pixel, sx;
@@ -766,6 +769,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
   L.has_hit = false;
   L.shading = false;
   L.item = 0;
+  L.slot = 0;
   L.pixel = 0;
   L.sx = 0;
   L.sy = 0;
@@ -793,7 +797,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       // Column complete: one 12-byte store; every item is written by exactly one lane.
       if (need && !L.need_item && L.sy >= A.s_row)
       {
-        store3(A.partial + 3u * (size_t)L.item, L.sum);
+        store3(A.partial + 3u * (size_t)L.slot, L.sum);
         L.need_item = true;
       }
       bool const ask = need && L.need_item;
@@ -808,6 +812,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             L.alive = false;
           else
           {
+            L.slot = info.slot;
             if (info.prepared)
             {
               L.item = info.item;

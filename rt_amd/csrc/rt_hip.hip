@@ -81,9 +81,10 @@ struct ItemPool
     end = next + kItemBatch;
   }
 
-  __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need)
+  __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need, uint32_t & slot)
   {
     uint32_t result = RT_INVALID;
+    slot = 0u;
     uint32_t const lane = __lane_id();
     for (;;)
     {
@@ -100,6 +101,7 @@ struct ItemPool
         unsigned long long const q = (unsigned long long)A.slice_index +
                                      (unsigned long long)A.slice_count * (unsigned long long)(next + rank);
         result = q < (unsigned long long)A.n_items ? (uint32_t)q : RT_INVALID;
+        slot = next + rank;
         need = false;
       }
       next += wanted < avail ? wanted : avail;
@@ -142,9 +144,10 @@ struct WaveEnv
     info.item = RT_INVALID;
     info.prepared = false;
     info.filter_tests = 0u;
+    info.slot = 0u;
     if (A.column_masks == 0u)
     {
-      info.item = pool.fetch(A, need);
+      info.item = pool.fetch(A, need, info.slot);
       return;
     }
     uint32_t const lane = __lane_id();
@@ -173,11 +176,11 @@ struct WaveEnv
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (need && rank < avail)
       {
-        uint32_t const slot = pool.next + rank - (pool.end - kItemBatch);
-        ColumnEntry const e = batch[slot];
+        ColumnEntry const e = batch[pool.next + rank - (pool.end - kItemBatch)];
         if (e.pixel != RT_INVALID)
         {
           info.item = e.pixel * A.s_row + e.sx;
+          info.slot = pool.next + rank;
           info.prepared = true;
           info.sdx = e.sdx;
           info.dyp = e.dyp;
@@ -209,7 +212,7 @@ struct BlockEnv
   {
     info.prepared = false;
     info.filter_tests = 0u;
-    info.item = pool.fetch(A, need);
+    info.item = pool.fetch(A, need, info.slot);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -337,26 +340,46 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
 }
 
 // The accumulate pass: per pixel, the column sums this slice owns are added in increasing sx (the order
-// Frame::ForEachRayImpl adds its outer loop, ray_tracing/frame.cpp:56).  partial: n * s_row interleaved RGB
-// column sums (a pixel's columns are contiguous: 12 * s_row bytes); planes: 3 planes of n floats.  One lane
-// per pixel.
+// Frame::ForEachRayImpl adds its outer loop, ray_tracing/frame.cpp:56).  partial holds the slice's column sums
+// (interleaved RGB) in slice order, so the columns a pixel owns are consecutive entries; planes: 3 planes of n
+// floats.  One lane per pixel.
 __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ partial, float * __restrict__ planes,
                                                      uint32_t n, uint32_t s_row, uint32_t slice_index,
                                                      uint32_t slice_count)
 {
   uint32_t const stride = gridDim.x * blockDim.x;
+  bool const wide = (s_row % slice_count) == 0u && ((s_row / slice_count) % 4u) == 0u;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
   {
-    size_t const first = (size_t)p * s_row;
+    unsigned long long const first = (unsigned long long)p * s_row;
     // first owned column: smallest sx with (first + sx) % slice_count == slice_index
     uint32_t const sx0 = (uint32_t)((slice_index + slice_count - (uint32_t)(first % slice_count)) % slice_count);
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    for (uint32_t sx = sx0; sx < s_row; sx += slice_count)
+    if (sx0 < s_row)
     {
-      const float * c = partial + 3u * (first + sx);
-      r += c[0];
-      g += c[1];
-      b += c[2];
+      size_t const k0 = (size_t)((first + sx0 - slice_index) / slice_count);
+      uint32_t const owned = (s_row - sx0 + slice_count - 1u) / slice_count;
+      const float * c = partial + 3u * k0;
+      if (wide)
+      {
+        // every pixel owns the same multiple of four columns: 48-byte groups, 16-byte aligned
+        const float4 * v = reinterpret_cast<const float4 *>(c);
+        for (uint32_t i = 0; i < owned; i += 4u, v += 3)
+        {
+          float4 const a0 = v[0], a1 = v[1], a2 = v[2];
+          r += a0.x; g += a0.y; b += a0.z;
+          r += a0.w; g += a1.x; b += a1.y;
+          r += a1.z; g += a1.w; b += a2.x;
+          r += a2.y; g += a2.z; b += a2.w;
+        }
+      }
+      else
+        for (uint32_t i = 0; i < owned; ++i, c += 3)
+        {
+          r += c[0];
+          g += c[1];
+          b += c[2];
+        }
     }
     planes[p] = r;
     planes[n + p] = g;
@@ -448,7 +471,7 @@ struct rt_hip_scene
 struct rt_hip_job
 {
   rt_hip_trace_params params;
-  float * d_partial = nullptr;  // width * height * samples_in_row column sums, RGB interleaved
+  float * d_partial = nullptr;  // the slice's column sums, RGB interleaved (partial_bytes)
   float * d_planes = nullptr;
   float * d_rgb = nullptr;
   unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
@@ -605,9 +628,12 @@ int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_
   return RT_HIP_OK;
 }
 
+// Column sums of one slice: 12 bytes per owned column.
 size_t partial_bytes(const rt_hip_trace_params * p)
 {
-  return 3 * sizeof(float) * (size_t)p->width * p->height * p->samples_in_row;
+  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
+  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
+  return 3 * sizeof(float) * (size_t)((items + g - 1u) / g);
 }
 
 int launch_resolve(const float * d_planes, float * d_rgb, uint32_t width, uint32_t height, uint32_t s_row,

@@ -23,6 +23,7 @@ struct HostEnv
   void fetch_item(bool need, rtc::ItemInfo & info)
   {
     info.item = rtc::RT_INVALID;
+    info.slot = 0;
     info.prepared = false;
     info.filter_tests = 0;
     if (!need)
@@ -31,6 +32,7 @@ struct HostEnv
     if (q >= total)
       return;
     info.item = (uint32_t)q;
+    info.slot = next - 1;
     if (A.column_masks != 0u)
     {
       rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, info.item);
@@ -140,7 +142,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
       float sum = 0.0f;
       for (uint32_t sx = 0; sx < s_row; ++sx)
         if (((unsigned long long)i * s_row + sx) % a.slice_count == a.slice_index)
-          sum += partial[3u * ((size_t)i * s_row + sx) + c];
+          sum += partial[3u * (size_t)(((unsigned long long)i * s_row + sx - a.slice_index) / a.slice_count) + c];
       rgb[3u * (size_t)i + c] = sum * inv;
     }
   if (stats6)
