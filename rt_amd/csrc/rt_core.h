@@ -116,6 +116,7 @@ RT_FN float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 RT_FN float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
 RT_FN float hw_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+RT_FN uint32_t hw_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 RT_FN int hw_clz(uint32_t x) { return __clz((int)x); }
 RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
@@ -131,6 +132,7 @@ RT_FN float hw_exp2(float x) { return exp2f(x); }
 RT_FN float hw_log2(float x) { return log2f(x); }
 RT_FN float hw_fma(float a, float b, float c) { return a * b + c; }
 RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+RT_FN uint32_t hw_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 RT_FN int hw_clz(uint32_t x) { return __builtin_clz(x); }
 RT_FN uint32_t f2u(float f)
 {
@@ -147,6 +149,7 @@ RT_FN float minf(float a, float b) { return (b < a) ? b : a; }  // std::min
 RT_FN float maxf(float a, float b) { return (a < b) ? b : a; }  // std::max
 RT_FN float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }
 RT_FN f3 normalize3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+RT_FN float fdot3(f3 a, f3 b) { return hw_fma(a.z, b.z, hw_fma(a.y, b.y, a.x * b.x)); }
 RT_FN f3 normalize3_fast(f3 v) { return v * hw_rsq(dot3(v, v)); }
 RT_FN f3 mix3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
 RT_FN float pow5(float x)
@@ -165,9 +168,9 @@ RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     uint32_t const lo0 = 0xD2511F53u * c0;
     uint32_t const hi1 = hw_mulhi(0xCD9E8D57u, c2);
     uint32_t const lo1 = 0xCD9E8D57u * c2;
-    c0 = hi1 ^ c1 ^ k0;
+    c0 = hw_xor3(hi1, c1, k0);
     c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
+    c2 = hw_xor3(hi0, c3, k1);
     c3 = lo0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
@@ -980,15 +983,36 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             jit[j] = jitter_ball(env.jitter_table(), k[0], k[1], k[2]);
           }
         }
-#pragma unroll
-        for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+        if (deterministic)
         {
-          f3 const rd = normalize3_fast(to_light + jit[j]);
-          dir[j] = rd;
-          a[j] = dot3(rd, rd);
-          rays_on |= 1u << j;
-          w[j] = maxf(0.0f, dot3(rd, L.hn));
+          // No jitter: the five shadow rays are one ray, normalised exactly as the reference does
+          // (ray_tracing/directional_light.cpp:20), so that a shadow edge never falls between two roundings.
+          f3 const rd = normalize3(to_light);
+          float const aa = dot3(rd, rd);
+          float const ww = maxf(0.0f, dot3(rd, L.hn));
+#pragma unroll
+          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+          {
+            dir[j] = rd;
+            a[j] = aa;
+            w[j] = ww;
+          }
         }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+          {
+            // jittered directions need no exact rounding: fused multiply-adds and the hardware rsqrt
+            f3 const v = to_light + jit[j];
+            float const inv = hw_rsq(fdot3(v, v));
+            f3 const rd = v * inv;
+            dir[j] = rd;
+            a[j] = fdot3(rd, rd);
+            w[j] = hw_max(0.0f, fdot3(rd, L.hn));
+          }
+        }
+        rays_on |= (1u << RT_LIGHT_SAMPLES) - 1u;
       }
       if (L.li == 0)
       {
