@@ -27,6 +27,13 @@ typedef struct rt_host_scene rt_host_scene;
 /* Builds demo `demo` from `seed` (synthetic_spheres is used by demo 3 only) and flattens it exactly as
  * DemoFrameHIP does before upload.  No device is touched. */
 int rt_host_scene_build(uint32_t demo, uint32_t seed, uint32_t synthetic_spheres, rt_host_scene ** out);
+/* A scene from / to a scene file (format: rt_amd/host/demos/scene_file.hpp).  Loading goes through the same
+ * objects and the same flattening as the demos; on a parse error returns non-zero with "file:line: what" in
+ * err.  Saving writes floats with nine significant digits, so a load gives back the same values. */
+int rt_host_scene_load(const char * path, rt_host_scene ** out, char * err, size_t err_len);
+int rt_host_scene_save(const char * path, const rt_hip_camera * camera, const float * centers_radii,
+                       const uint32_t * material_index, uint32_t sphere_count, const rt_hip_material * materials,
+                       uint32_t material_count, const rt_hip_light * lights, uint32_t light_count);
 void rt_host_scene_counts(const rt_host_scene * scene, uint32_t * spheres, uint32_t * materials,
                           uint32_t * lights);
 /* Copies the arrays out; each destination must hold the counts reported above (any may be NULL). */

@@ -16,6 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "librt_oracle.so")
 
 
+class OrcHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("position", C.c_float * 3), ("normal", C.c_float * 3), ("sphere", C.c_uint32)]
+
+
 class OrcScene(C.Structure):
     _fields_ = [
         ("spheres", C.c_void_p),
@@ -70,6 +74,12 @@ def load():
         lib.orc_sphere_trace_nearest.restype = C.c_int
         lib.orc_sphere_trace_nearest.argtypes = [C.POINTER(F3), C.POINTER(F3), C.POINTER(F3), C.c_float, C.c_float,
                                                  C.c_float, C.POINTER(C.c_float), C.POINTER(F3), C.POINTER(F3)]
+        lib.orc_sphere_trace.restype = C.c_int
+        lib.orc_sphere_trace.argtypes = [C.POINTER(F3), C.POINTER(F3), C.POINTER(F3), C.c_float, C.c_float, C.c_float,
+                                         C.POINTER(OrcHit)]
+        lib.orc_trace_all.restype = C.c_uint32
+        lib.orc_trace_all.argtypes = [C.POINTER(OrcScene), C.POINTER(F3), C.POINTER(F3), C.c_float, C.c_float,
+                                      C.POINTER(OrcHit), C.c_uint32]
         lib.orc_trace_nearest.restype = C.c_int
         lib.orc_trace_nearest.argtypes = [C.POINTER(OrcScene), C.POINTER(F3), C.POINTER(F3), C.c_float, C.c_float,
                                           C.POINTER(C.c_float), C.POINTER(F3), C.POINTER(F3)]

@@ -216,6 +216,90 @@ int orc_sphere_trace_nearest(const float origin[3], const float dir[3], const fl
   return 1;
 }
 
+/* Sphere::Trace, ray_tracing/sphere.cpp:11-61: every intersection in [tmin, tmax], nearest first (at most two;
+ * one when the discriminant is within kEps of zero).  Unused by either of the reference's backends; kept for
+ * the completeness of the HitableObject interface. */
+int orc_sphere_trace(const float origin[3], const float dir[3], const float center[3], float radius, float tmin,
+                     float tmax, orc_hit out[2])
+{
+  v3 const o = ld(origin), dv = ld(dir), cv = ld(center);
+  v3 const d = sub(o, cv);
+  float const a = dot(dv, dv);
+  float const b = 2.0f * dot(d, dv);
+  float const c = dot(d, d) - radius * radius;
+  float const disc = b * b - 4 * a * c;
+  float ts[2];
+  int n = 0;
+  if (disc < 0.0f)
+    return 0;
+  if (fabsf(disc) < ORC_EPS)
+  {
+    float const t = -b / (2.0f * a);
+    if (t < tmin || t > tmax)
+      return 0;
+    ts[n++] = t;
+  }
+  else
+  {
+    float const sq = sqrtf(disc);
+    float const t1 = (-b - sq) / (2.0f * a);
+    float const t2 = (-b + sq) / (2.0f * a);
+    int const has1 = (t1 >= tmin && t1 <= tmax);
+    int const has2 = (t2 >= tmin && t2 <= tmax);
+    if (has1 && has2)
+    {
+      ts[n++] = minf(t1, t2);
+      ts[n++] = maxf(t1, t2);
+    }
+    else if (has1)
+      ts[n++] = t1;
+    else if (has2)
+      ts[n++] = t2;
+  }
+  for (int i = 0; i < n; ++i)
+  {
+    v3 const p = add(o, muls(dv, ts[i]));
+    out[i].t = ts[i];
+    st(out[i].position, p);
+    st(out[i].normal, normalize(sub(p, cv)));
+    out[i].sphere = 0u;
+  }
+  return n;
+}
+
+/* TraceInHitableCollection, ray_tracing/hitable_object.hpp:53-69: the hits of all spheres, sorted by t
+ * (std::sort there; a stable insertion sort here, so equal t keep collection order).  Returns the number of
+ * hits, of which the first min(count, capacity) are stored. */
+uint32_t orc_trace_all(const orc_scene * scene, const float origin[3], const float dir[3], float tmin, float tmax,
+                       orc_hit * out, uint32_t capacity)
+{
+  uint32_t total = 0, stored = 0;
+  for (uint32_t i = 0; i < scene->sphere_count; ++i)
+  {
+    const float * s = scene->spheres + 4u * i;
+    orc_hit h[2];
+    int const n = orc_sphere_trace(origin, dir, s, s[3], tmin, tmax, h);
+    for (int k = 0; k < n; ++k)
+    {
+      total++;
+      h[k].sphere = i;
+      /* insert keeping the stored prefix sorted; drop the largest when full */
+      uint32_t pos = stored;
+      while (pos > 0 && out[pos - 1].t > h[k].t)
+        pos--;
+      if (pos >= capacity)
+        continue;
+      uint32_t const last = (stored < capacity) ? stored : capacity - 1u;
+      for (uint32_t j = last; j > pos; --j)
+        out[j] = out[j - 1];
+      out[pos] = h[k];
+      if (stored < capacity)
+        stored++;
+    }
+  }
+  return total;
+}
+
 typedef struct
 {
   float t;

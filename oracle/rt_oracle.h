@@ -119,6 +119,24 @@ void orc_primary_direction(const orc_camera * cam, uint32_t width, uint32_t heig
 int orc_sphere_trace_nearest(const float origin[3], const float dir[3], const float center[3], float radius,
                              float tmin, float tmax, float * out_t, float out_pos[3], float out_normal[3]);
 
+/* Hit, ray_tracing/hitable_object.hpp:15-30, with the sphere's index in place of its material pointer. */
+typedef struct
+{
+  float t;
+  float position[3];
+  float normal[3];
+  uint32_t sphere;
+} orc_hit;
+
+/* Sphere::Trace, ray_tracing/sphere.cpp:11-61: all intersections in [tmin, tmax], nearest first.  Returns 0..2. */
+int orc_sphere_trace(const float origin[3], const float dir[3], const float center[3], float radius, float tmin,
+                     float tmax, orc_hit out[2]);
+
+/* TraceInHitableCollection, ray_tracing/hitable_object.hpp:53-69: all hits of all spheres sorted by t.  Returns
+ * the total number of hits; the nearest min(total, capacity) are written to out. */
+uint32_t orc_trace_all(const orc_scene * scene, const float origin[3], const float dir[3], float tmin, float tmax,
+                       orc_hit * out, uint32_t capacity);
+
 /* TraceNearestInHitableCollection, ray_tracing/hitable_object.hpp:71-87.  Returns sphere index or -1. */
 int orc_trace_nearest(const orc_scene * scene, const float origin[3], const float dir[3], float tmin, float tmax,
                       float * out_t, float out_pos[3], float out_normal[3]);

@@ -105,6 +105,11 @@ HIP_SYMBOLS = {
 
 HOST_SYMBOLS = {
     "rt_host_scene_build": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rt_host_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "rt_host_scene_save": (
+        C.c_int,
+        [C.c_char_p, C.POINTER(Camera), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32],
+    ),
     "rt_host_scene_counts": (None, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_host_scene_copy": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera)]),
     "rt_host_scene_free": (None, [C.c_void_p]),
@@ -154,13 +159,7 @@ class Scene:
         return int(self.material_index.shape[0])
 
     @classmethod
-    def demo(cls, index, seed=1, spheres=10000):
-        """Demo `index` (1 pretty, 2 glass, 3 synthetic) as the C++ host builds and flattens it."""
-        host = load_host()
-        handle = C.c_void_p()
-        rc = host.rt_host_scene_build(index, seed, spheres, C.byref(handle))
-        if rc != 0:
-            raise RuntimeError("rt_host_scene_build(%d) failed with %d" % (index, rc))
+    def _from_handle(cls, host, handle):
         try:
             n, m, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
             host.rt_host_scene_counts(handle, C.byref(n), C.byref(m), C.byref(l))
@@ -176,6 +175,36 @@ class Scene:
         scene.material_count = m.value
         scene.light_count = l.value
         return scene
+
+    @classmethod
+    def demo(cls, index, seed=1, spheres=10000):
+        """Demo `index` (1 pretty, 2 glass, 3 synthetic) as the C++ host builds and flattens it."""
+        host = load_host()
+        handle = C.c_void_p()
+        rc = host.rt_host_scene_build(index, seed, spheres, C.byref(handle))
+        if rc != 0:
+            raise RuntimeError("rt_host_scene_build(%d) failed with %d" % (index, rc))
+        return cls._from_handle(host, handle)
+
+    @classmethod
+    def load(cls, path):
+        """A scene file (rt_amd/host/demos/scene_file.hpp), parsed and flattened by the C++ host."""
+        host = load_host()
+        handle = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = host.rt_host_scene_load(os.fsencode(path), C.byref(handle), err, 512)
+        if rc != 0:
+            raise ValueError("scene file: %s" % err.value.decode())
+        return cls._from_handle(host, handle)
+
+    def save(self, path):
+        host = load_host()
+        rc = host.rt_host_scene_save(os.fsencode(path), C.byref(self.camera), self.centers_radii.ctypes.data,
+                                     self.material_index.ctypes.data, self.sphere_count,
+                                     C.cast(self.materials, C.c_void_p), self.material_count,
+                                     C.cast(self.lights, C.c_void_p), self.light_count)
+        if rc != 0:
+            raise OSError("cannot write scene file %s" % path)
 
     @classmethod
     def build(cls, spheres, materials, lights, camera):

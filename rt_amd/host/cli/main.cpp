@@ -7,6 +7,7 @@
 // This binary has no CPU renderer: without a usable GPU it reports the error and exits with status 2.
 #include "demos/glass_spheres.hpp"
 #include "demos/pretty_spheres.hpp"
+#include "demos/scene_file.hpp"
 #include "demos/synthetic_spheres.hpp"
 #include "rt_hip/demo_frame_hip.hpp"
 
@@ -44,6 +45,8 @@ struct Options
   int device = -1;
   std::string out;
   std::string json;
+  std::string scene;      // --scene FILE: render this scene file instead of a built-in demo
+  std::string dumpScene;  // --dump-scene FILE: write the chosen scene to a scene file
 };
 
 bool ParseUint(char const * text, uint32_t & value)
@@ -104,6 +107,8 @@ bool ParseArgs(int argc, char * argv[], Options & o)
     else if (a == "--progress") o.progress = true;
     else if (a == "--out") { if (i + 1 >= argc) return false; o.out = argv[++i]; }
     else if (a == "--bench-json") { if (i + 1 >= argc) return false; o.json = argv[++i]; }
+    else if (a == "--scene") { if (i + 1 >= argc) return false; o.scene = argv[++i]; }
+    else if (a == "--dump-scene") { if (i + 1 >= argc) return false; o.dumpScene = argv[++i]; }
   }
   return true;
 }
@@ -171,6 +176,15 @@ int main(int argc, char * argv[])
   demosGpu.emplace_back(std::make_unique<demo::GlassSpheres>(makeFrame(), o.sceneSeed));
   demosGpu.emplace_back(std::make_unique<demo::SyntheticSpheres>(makeFrame(), o.spheres, o.sceneSeed));
 
+  demo::SceneFile * sceneFile = nullptr;
+  if (!o.scene.empty())
+  {
+    auto d = std::make_unique<demo::SceneFile>(makeFrame(), o.scene);
+    sceneFile = d.get();
+    demosGpu.emplace_back(std::move(d));
+    o.demoIndex = static_cast<uint32_t>(demosGpu.size());
+  }
+
   o.demoIndex = std::max(static_cast<uint32_t>(1), o.demoIndex);
   if (o.demoIndex > demosGpu.size())
   {
@@ -185,9 +199,24 @@ int main(int argc, char * argv[])
   if (!demo->Initialize(buffer, o.width, o.height, o.samplesInRow))
   {
     std::cout << "Demo initialization failed." << std::endl;
+    if (sceneFile != nullptr)
+      std::cout << sceneFile->Error() << std::endl;
     return 1;
   }
   auto & frame = demo->GetFrame();
+  if (!o.dumpScene.empty())
+  {
+    auto const & flat = hip->Scene();
+    auto const cam = hip->Camera();
+    if (!demo::WriteSceneFile(o.dumpScene, cam, flat.CentersRadii().data(), flat.MaterialIndex().data(),
+                              flat.SphereCount(), flat.Materials().data(),
+                              static_cast<uint32_t>(flat.Materials().size()), flat.Lights().data(),
+                              static_cast<uint32_t>(flat.Lights().size())))
+    {
+      std::cout << "Cannot write " << o.dumpScene << std::endl;
+      return 1;
+    }
+  }
 
   // High-quality mode raises the sample count to at least 20 per row on a GPU backend (app.cpp:92-99).
   if (o.highQuality)

@@ -2,6 +2,7 @@
 
 #include "demos/glass_spheres.hpp"
 #include "demos/pretty_spheres.hpp"
+#include "demos/scene_file.hpp"
 #include "demos/synthetic_spheres.hpp"
 #include "rt_hip/demo_frame_hip.hpp"
 
@@ -73,6 +74,40 @@ extern "C" int rt_host_scene_build(uint32_t demoIndex, uint32_t seed, uint32_t s
   scene->camera = frame->Camera();
   *out = scene;
   return 0;
+}
+
+extern "C" int rt_host_scene_load(const char * path, rt_host_scene ** out, char * err, size_t errLen)
+{
+  if (out == nullptr || path == nullptr)
+    return 1;
+  *out = nullptr;
+  demo::SceneFile d(std::make_unique<RecordingFrame>(), path);
+  auto buffer = std::make_shared<ray_tracing::ColorBuffer>(1);
+  if (!d.Initialize(buffer, 1, 1, 1))
+  {
+    if (err && errLen)
+      std::snprintf(err, errLen, "%s", d.Error().c_str());
+    return 2;
+  }
+  auto * frame = static_cast<RecordingFrame *>(d.GetFrame().get());
+  auto * scene = new rt_host_scene;
+  scene->flat = frame->m_flat;
+  scene->camera = frame->Camera();
+  *out = scene;
+  return 0;
+}
+
+extern "C" int rt_host_scene_save(const char * path, const rt_hip_camera * camera, const float * centersRadii,
+                                  const uint32_t * materialIndex, uint32_t sphereCount,
+                                  const rt_hip_material * materials, uint32_t materialCount,
+                                  const rt_hip_light * lights, uint32_t lightCount)
+{
+  if (path == nullptr || camera == nullptr)
+    return 1;
+  return demo::WriteSceneFile(path, *camera, centersRadii, materialIndex, sphereCount, materials, materialCount,
+                              lights, lightCount)
+             ? 0
+             : 2;
 }
 
 extern "C" void rt_host_scene_counts(const rt_host_scene * scene, uint32_t * spheres, uint32_t * materials,

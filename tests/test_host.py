@@ -71,3 +71,37 @@ def test_sharding_rule():
         owners = [sharding.owner_of(p, sx, s_row, count) for p in range(64) for sx in range(s_row)]
         per = np.bincount(owners, minlength=count)
         assert per.max() - per.min() <= 1  # balanced whatever divides what
+
+
+def test_scene_file_round_trip(ffi, scenes, tmp_path):
+    """Saving a flattened demo and loading it back through the C++ parser gives the same arrays, bit for bit
+    (material de-duplication may renumber nothing: the file already lists unique materials)."""
+    for demo in (1, 2):
+        scene = scenes(demo)
+        path = tmp_path / ("demo%d.rtscene" % demo)
+        scene.save(str(path))
+        back = ffi.Scene.load(str(path))
+        np.testing.assert_array_equal(back.centers_radii, scene.centers_radii)
+        np.testing.assert_array_equal(back.material_index, scene.material_index)
+        assert back.material_count == scene.material_count and back.light_count == scene.light_count
+        for i in range(scene.material_count):
+            a, b = scene.materials[i], back.materials[i]
+            assert (a.type, list(a.albedo), a.roughness, a.refraction) == (b.type, list(b.albedo), b.roughness, b.refraction)
+        for i in range(scene.light_count):
+            assert list(scene.lights[i].direction) == list(back.lights[i].direction)
+            assert list(scene.lights[i].color) == list(back.lights[i].color)
+        for field in ("position", "direction", "background"):
+            np.testing.assert_allclose(list(getattr(back.camera, field)), list(getattr(scene.camera, field)), rtol=3e-7)  # the direction is normalised again on load
+
+
+def test_scene_file_errors_name_the_line(ffi, tmp_path):
+    path = tmp_path / "bad.rtscene"
+    path.write_text("rt-scene 1\nmaterial a matte 1 1 1\nsphere 0 0 0 1 b\n")
+    with pytest.raises(ValueError, match=r"bad.rtscene:3: unknown material 'b'"):
+        ffi.Scene.load(str(path))
+    path.write_text("# nothing here\n")
+    with pytest.raises(ValueError, match="empty file"):
+        ffi.Scene.load(str(path))
+    path.write_text("scene\n")
+    with pytest.raises(ValueError, match="header"):
+        ffi.Scene.load(str(path))

@@ -1,4 +1,6 @@
 """Size-independent properties of the oracle's frame: what must hold whatever the scene."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -71,3 +73,69 @@ def test_counters_are_consistent(oracle, ffi, scenes):
     assert st.sphere_tests == st.ray_queries * scene.sphere_count
     # every sample asks one primary query; every shaded bounce asks five shadow queries and at most one more
     assert st.samples + 5 * st.shaded_bounces <= st.ray_queries <= st.samples + 6 * st.shaded_bounces
+
+
+def test_all_hits_of_one_sphere(oracle):
+    """Sphere::Trace (sphere.cpp:11-61): both roots in range, nearest first; one root when the other is out of
+    range; a grazing ray (|discriminant| < kEps) gives the single tangent point."""
+    lib = oracle.load()
+    hits = (oracle.OrcHit * 2)()
+    o, d, c = oracle.f3((0, 0, 0)), oracle.f3((0, 0, 1)), oracle.f3((0, 0, 5))
+    assert lib.orc_sphere_trace(C.byref(o), C.byref(d), C.byref(c), 1.0, 0.001, 1000.0, hits) == 2
+    assert hits[0].t == pytest.approx(4.0) and hits[1].t == pytest.approx(6.0)
+    np.testing.assert_allclose(list(hits[0].normal), (0, 0, -1), atol=1e-6)
+    np.testing.assert_allclose(list(hits[1].normal), (0, 0, 1), atol=1e-6)
+    np.testing.assert_allclose(list(hits[1].position), (0, 0, 6), atol=1e-6)
+    # far root only: the origin is inside the sphere
+    o = oracle.f3((0, 0, 5))
+    assert lib.orc_sphere_trace(C.byref(o), C.byref(d), C.byref(c), 1.0, 0.001, 1000.0, hits) == 1
+    assert hits[0].t == pytest.approx(1.0)
+    # near root only: tmax cuts the far one
+    o = oracle.f3((0, 0, 0))
+    assert lib.orc_sphere_trace(C.byref(o), C.byref(d), C.byref(c), 1.0, 0.001, 5.0, hits) == 1
+    assert hits[0].t == pytest.approx(4.0)
+    # tangent ray
+    o = oracle.f3((1, 0, 0))
+    assert lib.orc_sphere_trace(C.byref(o), C.byref(d), C.byref(c), 1.0, 0.001, 1000.0, hits) == 1
+    assert hits[0].t == pytest.approx(5.0)
+    # miss, and a sphere behind the origin
+    o = oracle.f3((2, 0, 0))
+    assert lib.orc_sphere_trace(C.byref(o), C.byref(d), C.byref(c), 1.0, 0.001, 1000.0, hits) == 0
+    o, c = oracle.f3((0, 0, 0)), oracle.f3((0, 0, -5))
+    assert lib.orc_sphere_trace(C.byref(o), C.byref(d), C.byref(c), 1.0, 0.001, 1000.0, hits) == 0
+
+
+def test_all_hits_of_a_collection_are_sorted_and_agree_with_nearest(oracle, scenes):
+    """TraceInHitableCollection (hitable_object.hpp:53-69) against TraceNearestInHitableCollection: when the
+    nearest-hit scan finds a sphere, it is the first entry of the sorted list whose t is that sphere's near root."""
+    lib = oracle.load()
+    scene = scenes(1)
+    osc = oracle.orc_scene(scene)
+    rng = np.random.default_rng(5)
+    cam = np.array(list(scene.camera.position), dtype=np.float64)
+    out = (oracle.OrcHit * 16)()
+    found = 0
+    for _ in range(300):
+        target = np.array([rng.uniform(-5, 5), rng.uniform(-1, 0), rng.uniform(-5, 5)])
+        direction = target - cam
+        direction /= np.linalg.norm(direction)
+        o, d = oracle.f3(cam), oracle.f3(direction)
+        total = lib.orc_trace_all(C.byref(osc), C.byref(o), C.byref(d), 0.001, 1000.0, out, 16)
+        ts = [out[i].t for i in range(min(total, 16))]
+        assert ts == sorted(ts)
+        t = C.c_float()
+        pos, nrm = oracle.F3(), oracle.F3()
+        idx = lib.orc_trace_nearest(C.byref(osc), C.byref(o), C.byref(d), 0.001, 1000.0, C.byref(t), C.byref(pos),
+                                    C.byref(nrm))
+        if idx >= 0:
+            found += 1
+            assert out[0].t == t.value and out[0].sphere == idx
+            np.testing.assert_array_equal(list(out[0].normal), list(nrm))
+    assert found > 100
+    # a small capacity keeps the nearest hits
+    o, d = oracle.f3(cam), oracle.f3(np.array([-2, -0.5, 2]) / np.linalg.norm([-2, -0.5, 2]))
+    total = lib.orc_trace_all(C.byref(osc), C.byref(o), C.byref(d), 0.001, 1000.0, out, 16)
+    small = (oracle.OrcHit * 2)()
+    assert lib.orc_trace_all(C.byref(osc), C.byref(o), C.byref(d), 0.001, 1000.0, small, 2) == total
+    for i in range(min(total, 2)):
+        assert small[i].t == out[i].t and small[i].sphere == out[i].sphere
