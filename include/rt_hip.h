@@ -42,6 +42,9 @@ extern "C" {
 
 /* Trace flags. */
 #define RT_HIP_FLAG_DETERMINISTIC 1u /* no stochastic scattering: ballRand == 0, glass branch draw == 0.5 */
+#define RT_HIP_FLAG_GRID 2u          /* rays walk a uniform grid over the spheres instead of testing every sphere
+                                        (scenes of 64 spheres or more; ignored for smaller ones).  Same image: the
+                                        grid only selects which spheres the exact intersection is run on. */
 
 /* Replaces CudaMaterial (rt_cuda/types_cuda.h): what Material::GetType/GetAlbedo/GetRoughness/
  * GetRefraction return (ray_tracing/material.hpp:20-26). */

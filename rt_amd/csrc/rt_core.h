@@ -36,11 +36,13 @@
 #include <hip/hip_runtime.h>
 #define RT_FN __device__ __forceinline__
 #define RT_HD __host__ __device__ __forceinline__
+#define RT_MEMBER __device__ __forceinline__
 #else
 #include <cmath>
 #include <cstring>
 #define RT_FN static inline
 #define RT_HD static inline
+#define RT_MEMBER inline
 #endif
 
 namespace rtc
@@ -59,6 +61,7 @@ constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c =
 
 constexpr uint32_t RT_MATTE = 0, RT_METAL = 1, RT_GLASS = 2;  // ray_tracing/types.hpp:15-17
 constexpr uint32_t RT_FLAG_DETERMINISTIC = 1u;
+constexpr uint32_t RT_FLAG_GRID = 2u;  // walk the scene's uniform grid instead of testing every sphere
 
 struct f3
 {
@@ -235,6 +238,16 @@ struct TraceArgs
   // col_delta bounds the distance between the middle direction and any sample direction of a column.
   uint32_t column_masks;      // 0: filter every primary ray on its own (col_delta is 0 then)
   float col_delta;
+  // Uniform grid over the spheres (optional; rt_prep.h build_grid).  Cell (x, y, z) holds the indices
+  // grid_items[grid_start[c] .. grid_start[c + 1]) with c = (z * dim.y + y) * dim.x + x, ascending; spheres too
+  // large for the grid are listed in grid_big and tested for every ray.
+  const uint32_t * grid_start;
+  const uint32_t * grid_items;
+  const uint32_t * grid_big;
+  uint32_t grid_big_count;
+  uint32_t grid_dim[3];
+  f3 grid_org;
+  float grid_cell, grid_inv_cell;
   // outputs
   float * partial;            // this slice's column sums, RGB interleaved, in slice order: item slice_index +
                               // slice_count * k is entry k (partial[3 * k + c])
@@ -247,7 +260,8 @@ struct TraceArgs
 #define RT_REGION_COUNT 12
 struct LaneCounters
 {
-  uint32_t samples, queries, hits, shaded, filter_tests, exact_tests;
+  uint32_t samples, queries, hits, shaded, exact_tests;
+  uint32_t filter_tests;  // rays (or columns) run through the filter; each is n_spheres tests
   uint32_t trips, rounds;  // loop trips and stage-P rounds this lane sat through, busy or not
 #if defined(RT_PROFILE_REGIONS)
   // Profiling builds only: wave clock ticks spent in each region of the loop (see RT_REGION).
@@ -366,7 +380,7 @@ struct ItemInfo
   bool prepared;
   float sdx, dyp;
   uint32_t cm0, cm1, pixel, sx;
-  uint32_t filter_tests;  // filter tests this lane executed while preparing columns (for anyone)
+  uint32_t filter_tests;  // columns this lane ran through the filter while preparing a batch (for anyone)
 };
 
 struct ColumnEntry
@@ -630,6 +644,144 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
 //                     tile_data(primary)
+// One axis of a walk through the uniform grid: the cell coordinate, the ray parameter at the next wall and
+// the parameter step from wall to wall.
+struct GridAxis
+{
+  float oo, dd, inv;  // origin relative to the grid, direction component and its reciprocal
+  int c, step;
+  float t_next, t_delta;
+
+  // Narrows [t0, t1] to the slab [0, extent]; false if the ray misses it.
+  RT_MEMBER bool clip(float origin, float dir, float extent, float & t0, float & t1)
+  {
+    oo = origin;
+    dd = dir;
+    if (dir == 0.0f)
+    {
+      inv = 0.0f;
+      return origin >= 0.0f && origin <= extent;
+    }
+    inv = 1.0f / dir;
+    float const ta = (0.0f - origin) * inv, tb = (extent - origin) * inv;
+    float const lo = (ta < tb) ? ta : tb, hi = (ta < tb) ? tb : ta;
+    t0 = (lo > t0) ? lo : t0;
+    t1 = (hi < t1) ? hi : t1;
+    return true;
+  }
+
+  RT_MEMBER void start(float t0, float cell, float inv_cell, int dim)
+  {
+    int ci = (int)floorf((oo + dd * t0) * inv_cell);
+    ci = ci < 0 ? 0 : (ci > dim - 1 ? dim - 1 : ci);
+    c = ci;
+    if (dd > 0.0f)
+    {
+      step = 1;
+      t_next = ((float)(ci + 1) * cell - oo) * inv;
+      t_delta = cell * inv;
+    }
+    else if (dd < 0.0f)
+    {
+      step = -1;
+      t_next = ((float)ci * cell - oo) * inv;
+      t_delta = -cell * inv;
+    }
+    else
+    {
+      step = 0;
+      t_next = 3.0e38f;
+      t_delta = 0.0f;
+    }
+  }
+
+  // Steps into the next cell; false when that leaves the grid.
+  RT_MEMBER bool advance(int dim)
+  {
+    c += step;
+    t_next += t_delta;
+    return c >= 0 && c < dim;
+  }
+};
+
+// One ray through the uniform grid.  any_hit: stop at the first sphere hit in [tmin, tmax] (shadow rays);
+// otherwise the nearest hit, the lowest sphere index among equal distances -- what the linear scan of
+// TraceNearestInHitableCollection (ray_tracing/hitable_object.hpp:71-87) returns.  Every candidate goes through
+// exact_hit, so distances are the brute-force ones bit for bit; the grid only decides which spheres are tried.
+// A sphere is listed in every cell its slightly inflated bounding box touches, so the cell that holds a hit
+// point always lists the sphere hit, whichever side of a cell wall rounding puts the walk on; the walk ends
+// once the best hit lies before the exit of the current cell.
+template <class Env>
+RT_FN void grid_trace(const TraceArgs & A, Env & env, bool active, f3 o, f3 d, float a, float tmin, float tmax,
+                      bool any_hit, float & best_t, int & best_i, LaneCounters & cnt)
+{
+  best_i = -1;
+  best_t = 0.0f;
+  if (!active)
+    return;
+  for (uint32_t k = 0; k < A.grid_big_count; ++k)
+  {
+    int const i = (int)A.grid_big[k];
+    float t;
+    cnt.exact_tests += 1;
+    if (exact_hit(o, d, a, env.sphere(i), tmin, tmax, t) && (best_i < 0 || t < best_t || (t == best_t && i < best_i)))
+    {
+      best_i = i;
+      best_t = t;
+      if (any_hit)
+        return;
+    }
+  }
+  // clip the ray to the grid's box (slabs), a little generously
+  float t0 = tmin, t1 = tmax;
+  GridAxis ax[3];
+  if (!ax[0].clip(o.x - A.grid_org.x, d.x, (float)A.grid_dim[0] * A.grid_cell, t0, t1) ||
+      !ax[1].clip(o.y - A.grid_org.y, d.y, (float)A.grid_dim[1] * A.grid_cell, t0, t1) ||
+      !ax[2].clip(o.z - A.grid_org.z, d.z, (float)A.grid_dim[2] * A.grid_cell, t0, t1))
+    return;
+  float const slack = 1e-4f * A.grid_cell;
+  if (t0 > t1 + slack)
+    return;
+  ax[0].start(t0, A.grid_cell, A.grid_inv_cell, (int)A.grid_dim[0]);
+  ax[1].start(t0, A.grid_cell, A.grid_inv_cell, (int)A.grid_dim[1]);
+  ax[2].start(t0, A.grid_cell, A.grid_inv_cell, (int)A.grid_dim[2]);
+  for (;;)
+  {
+    uint32_t const cell = ((uint32_t)ax[2].c * A.grid_dim[1] + (uint32_t)ax[1].c) * A.grid_dim[0] + (uint32_t)ax[0].c;
+    uint32_t const begin = A.grid_start[cell], end = A.grid_start[cell + 1u];
+    for (uint32_t k = begin; k < end; ++k)
+    {
+      int const i = (int)A.grid_items[k];
+      float t;
+      cnt.exact_tests += 1;
+      if (exact_hit(o, d, a, env.sphere(i), tmin, tmax, t) && (best_i < 0 || t < best_t || (t == best_t && i < best_i)))
+      {
+        best_i = i;
+        best_t = t;
+        if (any_hit)
+          return;
+      }
+    }
+    // leave through the nearest wall
+    bool const x_first = ax[0].t_next <= ax[1].t_next && ax[0].t_next <= ax[2].t_next;
+    bool const y_first = !x_first && ax[1].t_next <= ax[2].t_next;
+    float const t_exit = x_first ? ax[0].t_next : (y_first ? ax[1].t_next : ax[2].t_next);
+    if (best_i >= 0 && best_t <= t_exit - slack)
+      return;
+    if (t_exit > t1 + slack)
+      return;
+    bool inside;
+    if (x_first)
+      inside = ax[0].advance((int)A.grid_dim[0]);
+    else if (y_first)
+      inside = ax[1].advance((int)A.grid_dim[1]);
+    else
+      inside = ax[2].advance((int)A.grid_dim[2]);
+    if (!inside)
+      return;
+  }
+}
+
 template <class Env>
 RT_FN void resolve_primary(const TraceArgs & A, Env & env, uint32_t mask, uint32_t base, uint32_t count, f3 dir,
                            float a, float & best_t, int & best_i, LaneCounters & cnt)
@@ -651,10 +803,15 @@ RT_FN void resolve_primary(const TraceArgs & A, Env & env, uint32_t mask, uint32
 }
 
 // cm0, cm1: the column's candidate masks, used instead of a filter pass when A.column_masks is set.
-template <class Env>
+template <bool kGrid, class Env>
 RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, float a, uint32_t cm0, uint32_t cm1,
                          float & best_t, int & best_i, LaneCounters & cnt)
 {
+  if constexpr (kGrid)
+  {
+    grid_trace(A, env, active, A.cam_pos, dir, a, A.znear, A.zfar, false, best_t, best_i, cnt);
+    return;
+  }
   best_i = -1;
   best_t = 0.0f;
   if (A.column_masks != 0u)
@@ -685,15 +842,30 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
     }
   }
   if (active)
-    cnt.filter_tests += A.n_spheres;
+    cnt.filter_tests += 1u;
 }
 
 // rays_on: bit r set if ray r of this lane is to be traced.  Returns the shadow rays found occluded as bits
 // 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.
-template <class Env>
+template <bool kGrid, class Env>
 RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
                           uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
 {
+  if constexpr (kGrid)
+  {
+    uint32_t occluded = 0;
+#pragma unroll
+    for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
+    {
+      float t;
+      int i;
+      grid_trace(A, env, ((rays_on >> r) & 1u) != 0u, o, dir[r], a[r], 0.001f, 1000.0f, true, t, i, cnt);
+      occluded |= (i >= 0) ? (1u << r) : 0u;
+    }
+    grid_trace(A, env, ((rays_on >> (RT_RAYS - 1)) & 1u) != 0u, o, dir[RT_RAYS - 1], a[RT_RAYS - 1], 0.001f, A.zfar,
+               false, near_t, near_i, cnt);
+    return occluded;
+  }
   uint32_t live = rays_on;  // rays still looking for a hit
   near_i = -1;
   near_t = 0.0f;
@@ -756,11 +928,11 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       RT_REGION(cnt, 8);
     }
   }
-  cnt.filter_tests += (uint32_t)__builtin_popcount(rays_on) * A.n_spheres;
+  cnt.filter_tests += (uint32_t)__builtin_popcount(rays_on);
   return (rays_on & ~live) & ((1u << RT_LIGHT_SAMPLES) - 1u);
 }
 
-template <bool kForward, class Env>
+template <bool kForward, bool kGrid, class Env>
 RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t stride, LaneCounters & cnt)
 {
   Lane L;
@@ -848,7 +1020,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         float const a = dot3(d, d);
         float t;
         int hi;
-        trace_primary(A, env, active, d, a, L.cm0, L.cm1, t, hi, cnt);
+        trace_primary<kGrid>(A, env, active, d, a, L.cm0, L.cm1, t, hi, cnt);
         if (active)
         {
           cnt.samples += 1;
@@ -1025,7 +1197,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     float near_t;
     int near_i;
     RT_REGION(cnt, 9);
-    uint32_t const occluded = trace_pass(A, env, L.hp, dir, a, rays_on, near_t, near_i, cnt);
+    uint32_t const occluded = trace_pass<kGrid>(A, env, L.hp, dir, a, rays_on, near_t, near_i, cnt);
 
     if (in_pass)
     {

@@ -45,6 +45,7 @@ constexpr int kWavesPerSimdForward = 3;
 constexpr uint32_t kResidentMaterials = 256;  // resident scenes also keep their materials and lights in LDS
 constexpr uint32_t kResidentLights = 16;
 constexpr uint32_t kColumnMaskSpheres = 64;   // column masks: two 32-bit words per lane
+constexpr uint32_t kGridMinSpheres = 64;      // smaller scenes get no grid: testing every sphere is faster
 constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS whole (48 B per sphere)
 constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
 constexpr uint32_t kStatsWords = 8;
@@ -166,7 +167,7 @@ struct WaveEnv
         if (q < (unsigned long long)A.n_items)
         {
           e = prepare_column(A, cam, (uint32_t)q);
-          info.filter_tests += A.n_spheres;
+          info.filter_tests += 1u;
         }
         batch[lane] = e;
         __builtin_amdgcn_wave_barrier();
@@ -235,8 +236,37 @@ struct BlockEnv
   __device__ __forceinline__ const f4 * tile_data(bool) const { return tile; }
 };
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// Grid walks: every ray finds its own spheres, read from global memory (the L2 holds the scene); waves never
+// wait for each other.  The tile functions are unused.
+struct GridEnv
 {
+  const TraceArgs & A;
+  const float * jitter;  // LDS: RT_JITTER_FLOATS
+  ItemPool pool;
+
+  __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+  __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
+  __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
+  __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
+  {
+    info.prepared = false;
+    info.filter_tests = 0u;
+    info.item = pool.fetch(A, need, info.slot);
+  }
+  __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
+  __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+  __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[RT_MAT_RECORDS * m + k]; }
+  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
+  __device__ __forceinline__ const float * jitter_table() const { return jitter; }
+  __device__ __forceinline__ uint32_t tiles() const { return 0u; }
+  __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
+  __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return 0u; }
+  __device__ __forceinline__ const f4 * tile_data(bool) const { return nullptr; }
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t lane_value)
+{
+  unsigned long long v = lane_value;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
     v += __shfl_down(v, off);
@@ -246,6 +276,36 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 #if defined(RT_PROFILE_REGIONS)
 __device__ unsigned long long g_region_ticks[RT_REGION_COUNT];
 #endif
+
+// Work counters: one 64-bit atomic per wave and counter.
+__device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters & cnt)
+{
+  unsigned long long const c0 = wave_sum(cnt.samples);
+  unsigned long long const c1 = wave_sum(cnt.queries);
+  unsigned long long const c2 = wave_sum(cnt.hits);
+  unsigned long long const c3 = wave_sum(cnt.shaded);
+  unsigned long long const c4 = wave_sum(cnt.filter_tests) * A.n_spheres;
+  unsigned long long const c5 = wave_sum(cnt.exact_tests);
+  unsigned long long const c6 = wave_sum(cnt.trips);
+  unsigned long long const c7 = wave_sum(cnt.rounds);
+  if (A.stats != nullptr && __lane_id() == 0)
+  {
+    atomicAdd(&A.stats[0], c0);
+    atomicAdd(&A.stats[1], c1);
+    atomicAdd(&A.stats[2], c2);
+    atomicAdd(&A.stats[3], c3);
+    atomicAdd(&A.stats[4], c4);
+    atomicAdd(&A.stats[5], c5);
+    atomicAdd(&A.stats[6], c6);
+    atomicAdd(&A.stats[7], c7);
+  }
+#if defined(RT_PROFILE_REGIONS)
+  RT_REGION(cnt, 4);
+  if (__lane_id() == 0)
+    for (int k = 0; k < RT_REGION_COUNT; ++k)
+      atomicAdd(&g_region_ticks[k], cnt.region[k]);
+#endif
+}
 
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
@@ -268,7 +328,7 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
   {
     __syncthreads();
     BlockEnv env{A, sph, jitter, ItemPool()};
-    trace_loop<kForward>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    trace_loop<kForward, false>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
   {
@@ -289,35 +349,30 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
       lights[i] = A.lights[i];
     __syncthreads();
     WaveEnv env{A, sph, cam, exact, mats, lights, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
-    trace_loop<kForward>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    trace_loop<kForward, false>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
 
-  // Work counters: one 64-bit atomic per wave and counter.
-  uint32_t const c0 = wave_sum(cnt.samples);
-  uint32_t const c1 = wave_sum(cnt.queries);
-  uint32_t const c2 = wave_sum(cnt.hits);
-  uint32_t const c3 = wave_sum(cnt.shaded);
-  uint32_t const c4 = wave_sum(cnt.filter_tests);
-  uint32_t const c5 = wave_sum(cnt.exact_tests);
-  uint32_t const c6 = wave_sum(cnt.trips);
-  uint32_t const c7 = wave_sum(cnt.rounds);
-  if (A.stats != nullptr && __lane_id() == 0)
-  {
-    atomicAdd(&A.stats[0], (unsigned long long)c0);
-    atomicAdd(&A.stats[1], (unsigned long long)c1);
-    atomicAdd(&A.stats[2], (unsigned long long)c2);
-    atomicAdd(&A.stats[3], (unsigned long long)c3);
-    atomicAdd(&A.stats[4], (unsigned long long)c4);
-    atomicAdd(&A.stats[5], (unsigned long long)c5);
-    atomicAdd(&A.stats[6], (unsigned long long)c6);
-    atomicAdd(&A.stats[7], (unsigned long long)c7);
-  }
+  flush_counters(A, cnt);
+}
+
+// The same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).  LDS: [path stacks, unless
+// kForward][jitter table].
+template <bool kForward>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void trace_kernel_grid(TraceArgs A)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  f4 * stack = reinterpret_cast<f4 *>(lds_raw);
+  float * jitter = reinterpret_cast<float *>(stack + (kForward ? 0u : RT_MAX_DEPTH * kBlock));
+  for (uint32_t i = threadIdx.x; i < RT_JITTER_FLOATS; i += kBlock)
+    jitter[i] = A.jitter_tab[i];
+  __syncthreads();
+  LaneCounters cnt = {};
 #if defined(RT_PROFILE_REGIONS)
-  RT_REGION(cnt, 4);
-  if (__lane_id() == 0)
-    for (int k = 0; k < RT_REGION_COUNT; ++k)
-      atomicAdd(&g_region_ticks[k], cnt.region[k]);
+  cnt.last_tick = __builtin_amdgcn_s_memtime();
 #endif
+  GridEnv env{A, jitter, ItemPool()};
+  trace_loop<kForward, true>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+  flush_counters(A, cnt);
 }
 
 // The primary-ray filter table: per (padded) sphere, (centre - camera, filter bound).  One thread per entry.
@@ -466,6 +521,15 @@ struct rt_hip_scene
   f4 * d_lights = nullptr;
   uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
   bool forward_ok = false;  // paths can be accumulated forward (rt_prep.h forward_accumulation_ok)
+  // uniform grid for RT_HIP_FLAG_GRID traces (scenes of at least kGridMinSpheres spheres)
+  bool has_grid = false;
+  uint32_t * d_grid_start = nullptr;
+  uint32_t * d_grid_items = nullptr;
+  uint32_t * d_grid_big = nullptr;
+  uint32_t grid_big_count = 0;
+  uint32_t grid_dim[3] = {1, 1, 1};
+  float grid_org[3] = {0, 0, 0};
+  float grid_cell = 1.0f;
 };
 
 struct rt_hip_job
@@ -494,6 +558,8 @@ uint32_t forced_tile()
   return std::min(std::max(n, RT_PAD), kTileSpheres);
 }
 
+bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }
+
 bool is_tiled(const rt_hip_scene * sc)
 {
   return sc->n_padded > kResidentSpheres || sc->n_materials > kResidentMaterials || sc->n_lights > kResidentLights ||
@@ -507,9 +573,11 @@ bool uses_column_masks(const rt_hip_scene * sc)
 
 // Path stacks (scenes whose paths cannot be accumulated forward) + either the resident scene (filter, camera
 // table, exact records, materials, lights, one prepared-column table per wave) or one staging tile.
-size_t lds_bytes(const rt_hip_scene * sc)
+size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
 {
   size_t bytes = (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS;
+  if (uses_grid(sc, flags))
+    return bytes;
   if (is_tiled(sc))
     bytes += sizeof(f4) * (size_t)kTileSpheres;
   else
@@ -519,8 +587,10 @@ size_t lds_bytes(const rt_hip_scene * sc)
 }
 
 template <class Launch>
-auto with_trace_kernel(const rt_hip_scene * sc, Launch && go)
+auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
 {
+  if (uses_grid(sc, flags))
+    return sc->forward_ok ? go(trace_kernel_grid<true>) : go(trace_kernel_grid<false>);
   bool const tiled = is_tiled(sc);
   if (tiled)
     return sc->forward_ok ? go(trace_kernel<true, true>) : go(trace_kernel<true, false>);
@@ -529,11 +599,11 @@ auto with_trace_kernel(const rt_hip_scene * sc, Launch && go)
 
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
 // more lanes than work items.
-int persistent_blocks(const rt_hip_scene * sc, unsigned long long items)
+int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long long items)
 {
   int per_cu = 0;
-  size_t const lds = lds_bytes(sc);
-  hipError_t const e = with_trace_kernel(sc, [&](auto kernel) {
+  size_t const lds = lds_bytes(sc, flags);
+  hipError_t const e = with_trace_kernel(sc, flags, [&](auto kernel) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds);
   });
   if (e != hipSuccess || per_cu < 1)
@@ -593,7 +663,19 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
 
   RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
-  a.column_masks = uses_column_masks(scene) ? 1u : 0u;
+  if (uses_grid(scene, p->flags))
+  {
+    a.grid_start = scene->d_grid_start;
+    a.grid_items = scene->d_grid_items;
+    a.grid_big = scene->d_grid_big;
+    a.grid_big_count = scene->grid_big_count;
+    for (int k = 0; k < 3; ++k)
+      a.grid_dim[k] = scene->grid_dim[k];
+    a.grid_org = mk3(scene->grid_org[0], scene->grid_org[1], scene->grid_org[2]);
+    a.grid_cell = scene->grid_cell;
+    a.grid_inv_cell = 1.0f / scene->grid_cell;
+  }
+  a.column_masks = (uses_column_masks(scene) && !uses_grid(scene, p->flags)) ? 1u : 0u;
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
   if (scene->n_padded > 0)
   {
@@ -603,11 +685,11 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     RT_CHECK(hipGetLastError());
   }
   unsigned long long const my_items = ((unsigned long long)a.n_items + a.slice_count - 1u) / a.slice_count;
-  int const blocks = persistent_blocks(scene, my_items);
-  size_t const lds = lds_bytes(scene);
+  int const blocks = persistent_blocks(scene, p->flags, my_items);
+  size_t const lds = lds_bytes(scene, p->flags);
   if (ev_start)
     RT_CHECK(hipEventRecord(ev_start, stream));
-  with_trace_kernel(scene, [&](auto kernel) {
+  (void)with_trace_kernel(scene, p->flags, [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, stream, a);
     return hipSuccess;
   });
@@ -807,6 +889,27 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
     e = upload((void **)&s->d_materials, fs.materials.data(), fs.materials.size() * sizeof(f4));
   if (e == hipSuccess)
     e = upload((void **)&s->d_lights, fs.lights.data(), fs.lights.size() * sizeof(f4));
+  if (e == hipSuccess && sphere_count >= kGridMinSpheres)
+  {
+    GridHost g;
+    build_grid(centers_radii, sphere_count, g);
+    if (g.valid)
+    {
+      e = upload((void **)&s->d_grid_start, g.start.data(), g.start.size() * sizeof(uint32_t));
+      if (e == hipSuccess)
+        e = upload((void **)&s->d_grid_items, g.items.data(), g.items.size() * sizeof(uint32_t));
+      if (e == hipSuccess)
+        e = upload((void **)&s->d_grid_big, g.big.data(), g.big.size() * sizeof(uint32_t));
+      s->grid_big_count = static_cast<uint32_t>(g.big.size());
+      for (int k = 0; k < 3; ++k)
+      {
+        s->grid_dim[k] = g.dim[k];
+        s->grid_org[k] = g.org[k];
+      }
+      s->grid_cell = g.cell;
+      s->has_grid = (e == hipSuccess);
+    }
+  }
   if (e != hipSuccess)
   {
     rt_hip_scene_destroy(s);
@@ -826,6 +929,9 @@ void rt_hip_scene_destroy(rt_hip_scene * scene)
   if (scene->d_sphere_mat) (void)hipFree(scene->d_sphere_mat);
   if (scene->d_materials) (void)hipFree(scene->d_materials);
   if (scene->d_lights) (void)hipFree(scene->d_lights);
+  if (scene->d_grid_start) (void)hipFree(scene->d_grid_start);
+  if (scene->d_grid_items) (void)hipFree(scene->d_grid_items);
+  if (scene->d_grid_big) (void)hipFree(scene->d_grid_big);
   delete scene;
 }
 

@@ -98,6 +98,120 @@ inline void build_jitter_table(float * tab)
   }
 }
 
+// The uniform grid grid_trace walks.  Spheres much larger than the typical one (a ground sphere) stay out of it
+// and are tested for every ray.  Cells are cubes sized for a few spheres each and never smaller than a typical
+// sphere; a sphere is listed in every cell its bounding box, inflated by a thousandth of a cell, touches.
+struct GridHost
+{
+  bool valid = false;
+  float org[3] = {0, 0, 0};
+  float cell = 1.0f;
+  uint32_t dim[3] = {1, 1, 1};
+  std::vector<uint32_t> start;  // cells + 1
+  std::vector<uint32_t> items;
+  std::vector<uint32_t> big;
+};
+
+inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
+{
+  g = GridHost();
+  if (n < 2u)
+    return;
+  std::vector<float> radii(n);
+  for (uint32_t i = 0; i < n; ++i)
+    radii[i] = std::fabs(centers_radii[4u * i + 3u]);
+  std::vector<float> sorted(radii);
+  std::nth_element(sorted.begin(), sorted.begin() + n / 2u, sorted.end());
+  double const typical = std::max((double)sorted[n / 2u], 1e-6);
+  std::vector<uint32_t> small;
+  for (uint32_t i = 0; i < n; ++i)
+    (radii[i] > 16.0 * typical ? g.big : small).push_back(i);
+  if (small.empty() || g.big.size() > 64u)
+  {
+    g.big.clear();
+    return;
+  }
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (uint32_t i : small)
+    for (int k = 0; k < 3; ++k)
+    {
+      lo[k] = std::min(lo[k], (double)centers_radii[4u * i + k] - radii[i]);
+      hi[k] = std::max(hi[k], (double)centers_radii[4u * i + k] + radii[i]);
+    }
+  double ext[3];
+  for (int k = 0; k < 3; ++k)
+  {
+    double const pad = 1e-3 * (hi[k] - lo[k]) + 1e-3 * typical;
+    lo[k] -= pad;
+    hi[k] += pad;
+    ext[k] = hi[k] - lo[k];
+  }
+  // the largest cell that still gives about two cells per sphere, but at least a typical diameter
+  auto cells_for = [&](double s) {
+    double c = 1.0;
+    for (int k = 0; k < 3; ++k)
+      c *= std::max(1.0, std::ceil(ext[k] / s));
+    return c;
+  };
+  double s_lo = 2.0 * typical, s_hi = std::max({ext[0], ext[1], ext[2], s_lo});
+  double const want = 2.0 * (double)small.size();
+  if (cells_for(s_lo) > want)
+  {
+    for (int it = 0; it < 60; ++it)
+    {
+      double const mid = 0.5 * (s_lo + s_hi);
+      (cells_for(mid) > want ? s_lo : s_hi) = mid;
+    }
+    s_lo = s_hi;
+  }
+  s_lo = std::max(s_lo, std::max({ext[0], ext[1], ext[2]}) / 1024.0);  // at most 1024 cells along an axis
+  g.cell = (float)s_lo;
+  size_t cells = 1;
+  for (int k = 0; k < 3; ++k)
+  {
+    g.org[k] = (float)lo[k];
+    g.dim[k] = (uint32_t)std::max(1.0, std::ceil(ext[k] / (double)g.cell));
+    cells *= g.dim[k];
+  }
+  double const inflate = 1e-3 * (double)g.cell;
+  auto range = [&](uint32_t i, int k, int & a, int & b) {
+    double const c = (double)centers_radii[4u * i + k] - (double)g.org[k];
+    a = (int)std::floor((c - radii[i] - inflate) / (double)g.cell);
+    b = (int)std::floor((c + radii[i] + inflate) / (double)g.cell);
+    a = std::max(a, 0);
+    b = std::min(b, (int)g.dim[k] - 1);
+  };
+  std::vector<uint32_t> count(cells + 1u, 0u);
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    for (uint32_t i : small)  // ascending sphere index, so every cell's list comes out ascending
+    {
+      int x0, x1, y0, y1, z0, z1;
+      range(i, 0, x0, x1);
+      range(i, 1, y0, y1);
+      range(i, 2, z0, z1);
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y)
+          for (int x = x0; x <= x1; ++x)
+          {
+            size_t const c = ((size_t)z * g.dim[1] + (size_t)y) * g.dim[0] + (size_t)x;
+            if (pass == 0)
+              count[c + 1u]++;
+            else
+              g.items[count[c]++] = i;
+          }
+    }
+    if (pass == 0)
+    {
+      for (size_t c = 0; c < cells; ++c)
+        count[c + 1u] += count[c];
+      g.start = count;
+      g.items.resize(count[cells]);
+    }
+  }
+  g.valid = true;
+}
+
 // Scene records in the layout the kernel reads.
 struct FlatScene
 {

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(_HERE, "lib")
 
 FLAG_DETERMINISTIC = 1
+FLAG_GRID = 2
 
 RT_HIP_OK = 0
 RT_HIP_ERR_NOT_READY = 3

@@ -43,7 +43,7 @@ struct HostEnv
       info.cm1 = e.cm1;
       info.pixel = e.pixel;
       info.sx = e.sx;
-      info.filter_tests = A.n_spheres;
+      info.filter_tests = 1;
     }
   }
   rtc::f4 sphere(int i) const { return A.spheres[i]; }
@@ -65,7 +65,8 @@ struct HostEnv
 }  // namespace
 
 // tile_size: records per staged tile (exercises the multi-tile path when smaller than the scene).
-// mode: bit 0 = column masks (scenes of at most 64 spheres, one tile), bit 1 = forward accumulation.
+// mode: bit 0 = column masks (scenes of at most 64 spheres, one tile), bit 1 = forward accumulation,
+// bit 2 = rays walk the uniform grid.
 extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                                const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                                const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
@@ -129,10 +130,30 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   std::vector<rtc::f4> stack(rtc::RT_MAX_DEPTH);
   rtc::LaneCounters cnt{};
   HostEnv env{a, a.n_items, (tile_size && !column_masks) ? tile_size : (padded ? padded : 4u)};
-  if ((mode & 2u) != 0u)
-    rtc::trace_loop<true>(a, env, stack.data(), 1u, cnt);
+  rtc::GridHost grid;
+  if ((mode & 4u) != 0u)
+  {
+    rtc::build_grid(centers_radii, n, grid);
+    if (!grid.valid)
+      return 3;
+    a.grid_start = grid.start.data();
+    a.grid_items = grid.items.data();
+    a.grid_big = grid.big.data();
+    a.grid_big_count = static_cast<uint32_t>(grid.big.size());
+    for (int k = 0; k < 3; ++k)
+      a.grid_dim[k] = grid.dim[k];
+    a.grid_org = rtc::mk3(grid.org[0], grid.org[1], grid.org[2]);
+    a.grid_cell = grid.cell;
+    a.grid_inv_cell = 1.0f / grid.cell;
+    if ((mode & 2u) != 0u)
+      rtc::trace_loop<true, true>(a, env, stack.data(), 1u, cnt);
+    else
+      rtc::trace_loop<false, true>(a, env, stack.data(), 1u, cnt);
+  }
+  else if ((mode & 2u) != 0u)
+    rtc::trace_loop<true, false>(a, env, stack.data(), 1u, cnt);
   else
-    rtc::trace_loop<false>(a, env, stack.data(), 1u, cnt);
+    rtc::trace_loop<false, false>(a, env, stack.data(), 1u, cnt);
 
   // accumulate (owned columns in increasing sx) + resolve, as colsum_kernel and resolve_kernel do
   float const inv = 1.0f / static_cast<float>(s_row * s_row);
@@ -151,7 +172,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     stats6[1] = cnt.queries;
     stats6[2] = cnt.hits;
     stats6[3] = cnt.shaded;
-    stats6[4] = cnt.filter_tests;
+    stats6[4] = (unsigned long long)cnt.filter_tests * n;
     stats6[5] = cnt.exact_tests;
   }
   return 0;

@@ -151,3 +151,40 @@ def test_absorbing_metal_and_energy_break(oracle, ffi):
     out, es = emu_ffi.render(scene, p)
     assert np.abs(ref - out).mean() < 2e-5
     assert abs(es["shaded_bounces"] - rs.shaded_bounces) <= 2e-3 * rs.shaded_bounces
+
+
+@pytest.mark.parametrize("spheres", [100, 1500])
+@pytest.mark.parametrize("forward", [False, True])
+def test_grid_walk_finds_what_the_linear_scan_finds(oracle, ffi, scenes, spheres, forward):
+    """Rays walking the uniform grid: same hits, same counters and (stochastic mode included) the same frame as
+    testing every sphere, because every candidate still goes through the exact intersection."""
+    scene = scenes(3, 1, spheres)
+    for flags, s in ((ffi.FLAG_DETERMINISTIC, 2), (0, 2)):
+        p = ffi.params(48, 36, s, flags=flags, seed=6)
+        brute, sb = emu_ffi.render(scene, p, forward=forward)
+        grid, sg = emu_ffi.render(scene, p, forward=forward, grid=True)
+        np.testing.assert_array_equal(grid, brute)
+        for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces"):
+            assert sg[key] == sb[key], key
+        assert sg["exact_tests"] < 0.2 * sb["sphere_tests"]
+    ref, rs = oracle.render(scene, ffi.params(48, 36, 2, flags=ffi.FLAG_DETERMINISTIC, seed=6), 4)
+    out, es = emu_ffi.render(scene, ffi.params(48, 36, 2, flags=ffi.FLAG_DETERMINISTIC, seed=6), forward=forward, grid=True)
+    assert rel_err(ref, out).max() < 2e-6
+    assert es["ray_queries"] == rs.ray_queries and es["hit_queries"] == rs.hit_queries
+
+
+def test_grid_walk_with_rays_along_the_axes(oracle, ffi):
+    """Axis-parallel rays (zero direction components) and a camera inside the grid's box."""
+    mats = [(0, (0.7, 0.6, 0.5), 0.7, 0.0), (1, (0.9, 0.8, 0.3), 0.1, 0.15), (2, (0.3, 0.9, 0.8), 0.0, 0.85)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0)]
+    rng = np.random.default_rng(3)
+    for x in range(-4, 5):
+        for z in range(0, 9):
+            spheres.append((float(x), -0.6, float(z), 0.35 + 0.05 * float(rng.random()), int(rng.integers(0, 3))))
+    scene = ffi.Scene.build(spheres, mats, [((0.0, -1.0, 0.0), (1.0, 1.0, 1.0))],
+                            dict(position=(0.0, -0.6, 4.5), direction=(0.0, 0.0, 1.0), background=(0.8, 0.85, 0.9)))
+    p = ffi.params(33, 33, 1, flags=ffi.FLAG_DETERMINISTIC)  # the centre pixel looks straight down +z
+    ref, rs = oracle.render(scene, p, 2)
+    out, es = emu_ffi.render(scene, p, grid=True)
+    assert rel_err(ref, out).max() < 2e-6
+    assert es["hit_queries"] == rs.hit_queries

@@ -107,3 +107,27 @@ def test_cli_writes_the_frame(hip, ffi, scenes, tmp_path):
     subprocess.run(cmd[:-3] + ["--out", str(ppm)], check=True, capture_output=True, timeout=120)
     body = ppm.read_bytes().split(b"255\n", 1)[1]
     np.testing.assert_array_equal(np.frombuffer(body, dtype=np.uint8).reshape(64, 96, 3), ffi.update_texture(ref)[..., :3])
+
+
+def test_cli_renders_a_scene_file(hip, ffi, scenes, tmp_path):
+    """--dump-scene writes the chosen demo; --scene renders that file to the same frame.  (The light direction
+    and the already normalised camera direction survive the text form; re-normalising the latter moves it by an
+    ulp at most, hence the tolerance.)"""
+    cli = os.path.join(ROOT, "rt_amd", "bin", "rt_cli")
+    scene_path, a_path, b_path = tmp_path / "demo1.rtscene", tmp_path / "a.pfm", tmp_path / "b.pfm"
+    common = ["-w", "96", "-h", "64", "-s", "2", "--deterministic"]
+    subprocess.run([cli, "-d", "1", "--dump-scene", str(scene_path), "--out", str(a_path)] + common, check=True,
+                   capture_output=True, timeout=120)
+    res = subprocess.run([cli, "--scene", str(scene_path), "--out", str(b_path)] + common, capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+    def read(path):
+        return np.frombuffer(path.read_bytes().split(b"-1.0\n", 1)[1], dtype="<f4").reshape(64, 96, 3)
+
+    np.testing.assert_allclose(read(b_path), read(a_path), rtol=1e-4, atol=1e-6)
+    assert ffi.Scene.load(str(scene_path)).sphere_count == 41
+    bad = tmp_path / "bad.rtscene"
+    bad.write_text("rt-scene 1\nsphere 0 0 0 1 nope\n")
+    res = subprocess.run([cli, "--scene", str(bad)] + common, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 1 and "unknown material" in res.stdout

@@ -184,3 +184,30 @@ def test_full_size_frame_properties(hip, ffi, scenes):
     assert np.isfinite(a).all() and a.min() >= 0.0
     # the low-resolution oracle render of the same view has the same mean radiance
     assert abs(float(a.mean()) - 0.746) < 0.01
+
+
+@pytest.mark.parametrize("spheres", [300, 3000])
+def test_grid_walk_equals_testing_every_sphere(hip, oracle, ffi, scenes, spheres):
+    """RT_HIP_FLAG_GRID only changes which spheres the exact intersection is run on: the frame and the query
+    counters are those of the brute-force trace, bit for bit, in both modes."""
+    scene = scenes(3, 1, spheres)
+    for flags, seed in ((ffi.FLAG_DETERMINISTIC, 1), (0, 5)):
+        p = ffi.params(96, 72, 2, flags=flags, seed=seed)
+        brute, sb = hip.render(scene, p)
+        grid, sg = hip.render(scene, ffi.params(96, 72, 2, flags=flags | ffi.FLAG_GRID, seed=seed))
+        np.testing.assert_array_equal(grid, brute)
+        assert (sg.samples, sg.ray_queries, sg.hit_queries, sg.shaded_bounces) == \
+               (sb.samples, sb.ray_queries, sb.hit_queries, sb.shaded_bounces)
+        assert sg.sphere_tests == 0 and sg.exact_tests < 0.05 * sb.sphere_tests
+    p = ffi.params(96, 72, 2, flags=ffi.FLAG_DETERMINISTIC | ffi.FLAG_GRID)
+    ref, rs = oracle.render(scene, ffi.params(96, 72, 2, flags=ffi.FLAG_DETERMINISTIC))
+    out, st = hip.render(scene, p)
+    assert rel_err(ref, out).max() < 1e-4 and st.hit_queries == rs.hit_queries
+
+
+def test_grid_flag_is_ignored_for_small_scenes(hip, ffi, scenes):
+    scene = scenes(1)
+    a, sa = hip.render(scene, ffi.params(64, 48, 2, seed=2))
+    b, sb = hip.render(scene, ffi.params(64, 48, 2, seed=2, flags=ffi.FLAG_GRID))
+    np.testing.assert_array_equal(a, b)
+    assert sa.sphere_tests == sb.sphere_tests > 0

@@ -11,7 +11,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kIters = 4096;
 constexpr int kChains = 8;
 
-enum Op { FMA, PKFMA, MULHI, MULLO, MAD64, SQRT, RCP, RSQ, CMPSEL, PHILOX, ADD, EXP2, SINREV, CMPADDC, ALIGNBIT, FILT_OLD, FILT_NEW, SFMA };
+enum Op { FMA, PKFMA, MULHI, MULLO, MAD64, SQRT, RCP, RSQ, CMPSEL, PHILOX, ADD, EXP2, SINREV, CMPADDC, ALIGNBIT, FILT_OLD, FILT_NEW, SFMA, PERM, PKRTZ, ANDOR, LSHLOR, BFI, CNDMASK, MED3, MAX3, LSHR };
 
 template <int OP>
 __global__ __launch_bounds__(256) void bench(float * out, float seed)
@@ -53,6 +53,19 @@ __global__ __launch_bounds__(256) void bench(float * out, float seed)
         float const t = __builtin_fmaf(x[i], a, __builtin_fmaf(x[i], b, __builtin_fmaf(x[i], seed, -b)));
         u[i] = __builtin_amdgcn_alignbit(u[i], __float_as_uint(t), 31);
       }
+      if (OP == PERM) u[i] = __builtin_amdgcn_perm(u[i], __float_as_uint(a), 0x07030501u + (uint32_t)it);
+      if (OP == PKRTZ)
+      {
+        auto h = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(u[i]), a);
+        u[i] = __builtin_bit_cast(uint32_t, h) + 0x3F800000u;
+      }
+      if (OP == ANDOR) u[i] = (u[i] & 0x80808080u) | (uint32_t)it;
+      if (OP == LSHLOR) u[i] = (u[i] << 1) | (uint32_t)it;
+      if (OP == BFI) u[i] = (u[i] & 0x0F0F0F0Fu) | (u[(i + 1) % kChains] & ~0x0F0F0F0Fu);
+      if (OP == CNDMASK) x[i] = (u[i] & 1u) ? x[i] : x[(i + 1) % kChains];
+      if (OP == MED3) x[i] = __builtin_amdgcn_fmed3f(x[i], a, b + (float)it);
+      if (OP == MAX3) x[i] = fmaxf(fmaxf(x[i], a), b - (float)it);
+      if (OP == LSHR) u[i] = (u[i] >> 1) + 0x9E3779B9u;
       if (OP == SFMA) x[i] = __builtin_fmaf(x[i], a, x[(i + 1) % kChains]);
       if (OP == PHILOX)
       {
@@ -150,6 +163,15 @@ int main(int argc, char ** argv)
   run<FILT_OLD>("filt_old", 5, blocks, d_out);
   run<FILT_NEW>("filt_new", 4, blocks, d_out);
   run<SFMA>("fma_dep", 1, blocks, d_out);
+  run<PERM>("perm", 1, blocks, d_out);
+  run<PKRTZ>("pkrtz+xor", 2, blocks, d_out);
+  run<ANDOR>("and_or", 1, blocks, d_out);
+  run<LSHLOR>("lshl_or", 1, blocks, d_out);
+  run<BFI>("bfi", 1, blocks, d_out);
+  run<CNDMASK>("and+cnd", 2, blocks, d_out);
+  run<MED3>("med3", 1, blocks, d_out);
+  run<MAX3>("max3", 1, blocks, d_out);
+  run<LSHR>("lshr+add", 2, blocks, d_out);
   hipFree(d_out);
   return 0;
 }
