@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--samples", type=int, default=16, help="samples per row: S x S per pixel")
     ap.add_argument("--demo", type=int, default=1, help="1 pretty_spheres, 2 glass_spheres, 3 synthetic field")
     ap.add_argument("--spheres", type=int, default=10000, help="sphere count of demo 3")
+    ap.add_argument("--grid", action="store_true", help="rays walk the scene's uniform grid (scenes of 64+ spheres)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,8 +99,9 @@ def main():
     renderer = ffi.HipRenderer(local_rank)  # raises if librt_hip.so or the GPU is missing: no fallback
     scene = ffi.Scene.demo(args.demo, 1, args.spheres)
     w, h, s = args.width, args.height, args.samples
-    p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1), rank, world)
-    full = ffi.params(w, h, s, seed=1)
+    flags = ffi.FLAG_GRID if args.grid else 0
+    p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world)
+    full = ffi.params(w, h, s, seed=1, flags=flags)
 
     device = torch.device("cuda", local_rank)
     planes = torch.empty(3 * w * h, dtype=torch.float32, device=device)
@@ -171,6 +173,7 @@ def main():
                 "scene_seed": 1,
                 "render_seed": 1,
                 "max_depth": 10,
+                "intersection": "uniform grid" if args.grid else "every sphere (LDS-resident or LDS-tiled)",
             },
             "mrays_per_s": round(stats["ray_queries"] / (elapsed / args.steps) / 1e6, 1),
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),
