@@ -506,6 +506,7 @@ struct Library
   size_t workspace_bytes = 0;
   uint32_t * never_cancel = nullptr;  // a zero word for traces that cannot be cancelled
   float * jitter_tab = nullptr;       // RT_JITTER_FLOATS, see rt_core.h jitter_ball
+  rt_hip_job * spare_job = nullptr;   // buffers of the last finished job, see free_job
 };
 Library g_lib;
 
@@ -535,6 +536,8 @@ struct rt_hip_scene
 struct rt_hip_job
 {
   rt_hip_trace_params params;
+  size_t partial_size = 0;  // bytes behind d_partial
+  size_t pixels = 0;        // pixels behind d_planes / d_rgb
   float * d_partial = nullptr;  // the slice's column sums, RGB interleaved (partial_bytes)
   float * d_planes = nullptr;
   float * d_rgb = nullptr;
@@ -742,7 +745,7 @@ void read_stats(const unsigned long long * h, rt_hip_stats * out)
   out->lane_rounds = h[7];
 }
 
-void free_job(rt_hip_job * job)
+void destroy_job(rt_hip_job * job)
 {
   if (job == nullptr)
     return;
@@ -754,6 +757,73 @@ void free_job(rt_hip_job * job)
   if (job->start) (void)hipEventDestroy(job->start);
   if (job->stop) (void)hipEventDestroy(job->stop);
   delete job;
+}
+
+// A finished job's buffers are kept for the next frame of the same size (a viewer renders the same frame
+// size over and over; allocating 400 MB and a pinned word per frame would cost more than a small frame).
+void free_job(rt_hip_job * job)
+{
+  if (job == nullptr)
+    return;
+  rt_hip_job * evicted = job;
+  {
+    std::lock_guard<std::mutex> lock(g_lib.mutex);
+    if (g_lib.ready && job->d_partial && job->d_planes && job->d_rgb && job->d_stats && job->h_cancel && job->start &&
+        job->stop)
+    {
+      evicted = g_lib.spare_job;
+      g_lib.spare_job = job;
+    }
+  }
+  destroy_job(evicted);
+}
+
+// A job object with buffers for `params`: the spare one if it fits, else a fresh one.
+rt_hip_job * acquire_job(const rt_hip_trace_params * params, hipError_t & e)
+{
+  size_t const need = partial_bytes(params);
+  size_t const pixels = (size_t)params->width * params->height;
+  rt_hip_job * job = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_lib.mutex);
+    if (g_lib.spare_job != nullptr && g_lib.spare_job->partial_size >= need && g_lib.spare_job->pixels == pixels)
+    {
+      job = g_lib.spare_job;
+      g_lib.spare_job = nullptr;
+    }
+  }
+  e = hipSuccess;
+  if (job != nullptr)
+  {
+    job->cancelled = false;
+    job->params = *params;
+    *job->h_cancel = 0u;
+    return job;
+  }
+  job = new (std::nothrow) rt_hip_job;
+  if (job == nullptr)
+  {
+    e = hipErrorOutOfMemory;
+    return nullptr;
+  }
+  job->params = *params;
+  job->partial_size = need;
+  job->pixels = pixels;
+  e = hipMalloc((void **)&job->d_partial, std::max<size_t>(need, 16));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_rgb, 3 * pixels * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
+  if (e == hipSuccess) e = hipEventCreate(&job->start);
+  if (e == hipSuccess) e = hipEventCreate(&job->stop);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&job->h_cancel, 64, hipHostMallocMapped);
+  if (e == hipSuccess)
+    *job->h_cancel = 0u;
+  else
+  {
+    destroy_job(job);
+    job = nullptr;
+  }
+  return job;
 }
 }  // namespace
 
@@ -815,6 +885,8 @@ void rt_hip_shutdown(void)
   (void)hipStreamSynchronize(g_lib.copy_stream);
   (void)hipStreamDestroy(g_lib.stream);
   (void)hipStreamDestroy(g_lib.copy_stream);
+  destroy_job(g_lib.spare_job);
+  g_lib.spare_job = nullptr;
   if (g_lib.workspace) (void)hipFree(g_lib.workspace);
   g_lib.workspace = nullptr;
   g_lib.workspace_bytes = 0;
@@ -945,24 +1017,12 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
   if (rc != RT_HIP_OK)
     return rc;
 
-  rt_hip_job * job = new (std::nothrow) rt_hip_job;
+  hipError_t e = hipSuccess;
+  rt_hip_job * job = acquire_job(params, e);
   if (job == nullptr)
-    return fail(RT_HIP_ERR_DEVICE, "out of host memory");
-  job->params = *params;
-  size_t const pixels = (size_t)params->width * params->height;
-  hipError_t e = hipMalloc((void **)&job->d_partial, partial_bytes(params));
-  if (e == hipSuccess) e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void **)&job->d_rgb, 3 * pixels * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
-  if (e == hipSuccess) e = hipEventCreate(&job->start);
-  if (e == hipSuccess) e = hipEventCreate(&job->stop);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&job->h_cancel, 64, hipHostMallocMapped);
+    return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   uint32_t * d_cancel = nullptr;
-  if (e == hipSuccess)
-  {
-    *job->h_cancel = 0u;
-    e = hipHostGetDevicePointer((void **)&d_cancel, job->h_cancel, 0);
-  }
+  e = hipHostGetDevicePointer((void **)&d_cancel, job->h_cancel, 0);
   // Unfinished columns read as black in snapshots.
   if (e == hipSuccess) e = hipMemsetAsync(job->d_partial, 0, partial_bytes(params), g_lib.stream);
   if (e != hipSuccess)
