@@ -253,6 +253,7 @@ struct TraceArgs
                               // slice_count * k is entry k (partial[3 * k + c])
   uint32_t n_items;           // width * height * s_row
   uint32_t * queue_counter;   // next work item of this slice to hand out
+  uint32_t batch_items;       // queue positions a wave reserves at a time
   const uint32_t * cancel;    // non-zero: stop handing out work (host-visible memory, read on refills only)
   unsigned long long * stats; // counters, see rt_hip.hip
 };

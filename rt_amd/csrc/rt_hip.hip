@@ -52,33 +52,40 @@ constexpr uint32_t kStatsWords = 8;
 
 // ---------------------------------------------------------------- device side
 
-// Work items come from one frame-wide counter, but a wave only touches it once per kItemBatch items: it
-// reserves a batch and then serves its lanes from that pool with a ballot and a prefix count (a single
-// counter word sustains well under a hundred dequeues per microsecond, far fewer than the waves ask for).
-// The k-th item of slice r out of g is r + g * k.
+// Work items come from one frame-wide counter, but a wave only touches it once per A.batch_items items (a
+// multiple of kItemBatch chosen by the host: a single counter word sustains well under a hundred reservations
+// per microsecond, far fewer than the waves would ask for item by item, or even batch by batch when columns
+// are short).  The wave works through its reservation in windows of kItemBatch, serving its lanes from the
+// window with a ballot and a prefix count.  The k-th item of slice r out of g is r + g * k.
 constexpr uint32_t kItemBatch = 64;
 constexpr uint32_t kCancelPoll = 8;
 
 struct ItemPool
 {
-  uint32_t next = 0, end = 0;  // wave-uniform
+  uint32_t next = 0, end = 0;  // the current window, wave-uniform
+  uint32_t reserved_end = 0;   // end of the wave's reservation
   uint32_t refills = 0;
 
-  // Reserves the next batch of queue positions for the wave.
+  // Opens the next window: the rest of the reservation, or a new reservation.
   __device__ __forceinline__ void refill(const TraceArgs & A)
   {
-    uint32_t base = 0;
-    if (__lane_id() == 0)
+    if (end == reserved_end)
     {
-      // A cancelled job stops at a refill: the wave is sent past the end of the queue.  The flag may live
-      // in host memory, a slow read, so only every kCancelPoll-th refill looks at it.
-      bool cancelled = false;
-      if ((refills % kCancelPoll) == 0u)
-        cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-      base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, kItemBatch);
+      uint32_t base = 0;
+      if (__lane_id() == 0)
+      {
+        // A cancelled job stops at a reservation: the wave is sent past the end of the queue.  The flag may
+        // live in host memory, a slow read, so only every kCancelPoll-th reservation looks at it.
+        bool cancelled = false;
+        if ((refills % kCancelPoll) == 0u)
+          cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, A.batch_items);
+      }
+      refills += 1u;
+      end = __builtin_amdgcn_readfirstlane(base);
+      reserved_end = end + A.batch_items;
     }
-    refills += 1u;
-    next = __builtin_amdgcn_readfirstlane(base);
+    next = end;
     end = next + kItemBatch;
   }
 
@@ -617,6 +624,20 @@ int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long lon
   return (int)blocks;
 }
 
+// Items per queue reservation: about 1024 samples' worth (16 columns of 64 ... one column of 1024 samples),
+// but few enough that every wave of a full grid still makes several reservations (load balance at the end of
+// the frame), and always a multiple of the window.
+uint32_t batch_items(const rt_hip_trace_params * p, int compute_units)
+{
+  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
+  unsigned long long const items = ((unsigned long long)p->width * p->height * p->samples_in_row + g - 1u) / g;
+  unsigned long long const waves = (unsigned long long)std::max(compute_units, 1) * 4u * kWavesPerSimd;
+  unsigned long long k = (1024u + kItemBatch * p->samples_in_row - 1u) / (kItemBatch * p->samples_in_row);
+  unsigned long long const balance = items / (waves * kItemBatch * 4u);
+  k = std::max<unsigned long long>(1u, std::min(k, balance));
+  return (uint32_t)(k * kItemBatch);
+}
+
 int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p)
 {
   if (!g_lib.ready)
@@ -664,6 +685,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
+  a.batch_items = batch_items(p, g_lib.compute_units);
 
   RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
   if (uses_grid(scene, p->flags))
