@@ -55,7 +55,8 @@ constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
 constexpr uint32_t RT_PAD = 1;         // sphere arrays are padded to a multiple of this with never-hit entries
 constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
-constexpr uint32_t RT_UNROLL = 4;      // spheres per trip of the filter loops' main part
+constexpr uint32_t RT_UNROLL = 2;      // spheres per trip of the filter loops' main part (4 costs a dozen registers
+                                       // more, which is the difference between three and four waves per SIMD)
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
 
