@@ -348,6 +348,7 @@ struct Lane
   float e, m_refraction, s_a;
   float nx_t;
   int nx_i;  // nearest hit of the scattered ray (found during the first light's pass)
+  u4 shadow_words;  // Philox block of the first light's shadow jitter, drawn with the scatter block
 };
 
 // Frame::ForEachRayImpl, ray_tracing/frame.cpp:61-62: direction of sub-sample (sx, sy) given the column's sdx.
@@ -939,6 +940,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 {
   Lane L;
   L.cm0 = L.cm1 = 0u;
+  L.shadow_words.x = L.shadow_words.y = L.shadow_words.z = L.shadow_words.w = 0u;
   L.acc_l = mk3(0.0f, 0.0f, 0.0f);
   L.acc_e = 1.0f;
   L.alive = true;
@@ -1096,7 +1098,10 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       float xi = 0.5f;
       if (!deterministic)
       {
+        // The first light's shadow block is drawn here too: the two Philox chains are independent and
+        // interleave, where each alone is a long run of dependent instructions.
         u4 const rw = philox4x32_10(L.depth, 0u, L.sample, 0u, L.pixel, A.seed);
+        L.shadow_words = philox4x32_10(L.depth, 1u, L.sample, 0u, L.pixel, A.seed);
         ball = ball3(1.0f, uniform24(rw.x), uniform24(rw.y), uniform24(rw.z));
         xi = uniform24(rw.w);
       }
@@ -1142,7 +1147,9 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         if (!deterministic)
         {
           // 15 cells of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
-          u4 const p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
+          u4 p0 = L.shadow_words;
+          if (L.li != 0u)
+            p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
           uint32_t const wd[4] = {p0.x, p0.y, p0.z, p0.w};
 #pragma unroll
           for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
