@@ -55,8 +55,7 @@ constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
 constexpr uint32_t RT_PAD = 1;         // sphere arrays are padded to a multiple of this with never-hit entries
 constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
-constexpr uint32_t RT_UNROLL = 2;      // spheres per trip of the filter loops' main part (4 costs a dozen registers
-                                       // more, which is the difference between three and four waves per SIMD)
+constexpr uint32_t RT_UNROLL = 2;      // camera-table entries per trip of the primary filter's main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
 
@@ -608,16 +607,17 @@ RT_FN void filter_sphere_6(f4 s, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask
 }
 
 // Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK, a multiple of RT_PAD) spheres.
+template <uint32_t kUnroll>
 RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask)[RT_RAYS])
 {
 #pragma unroll
   for (int r = 0; r < RT_RAYS; ++r)
     mask[r] = 0;
   uint32_t j = 0;
-  for (; j + RT_UNROLL <= count; j += RT_UNROLL)
+  for (; j + kUnroll <= count; j += kUnroll)
   {
 #pragma unroll
-    for (uint32_t u = 0; u < RT_UNROLL; ++u)
+    for (uint32_t u = 0; u < kUnroll; ++u)
       filter_sphere_6(sph[j + u], o, dir, mask);
   }
   for (; j < count; ++j)
@@ -636,6 +636,8 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 }
 
 // What the enclosing kernel provides (Env):
+//   kFilterUnroll     spheres per trip of the six-ray filter's main loop (4 costs a dozen registers more than
+//                     2, the difference between three and four waves per SIMD)
 //   any(p)            true if p holds for any lane sharing this lane's loop trips (the wave; the block when
 //                     sphere tiles are re-staged inside the loop)
 //   count(p)          number of such lanes for which p holds
@@ -882,7 +884,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
       uint32_t mask[RT_RAYS];
       RT_REGION(cnt, 6);
-      filter_chunk_6(sph + c0, count, o, dir, mask);
+      filter_chunk_6<Env::kFilterUnroll>(sph + c0, count, o, dir, mask);
       RT_REGION(cnt, 7);
       uint32_t any_mask = 0;
 #pragma unroll

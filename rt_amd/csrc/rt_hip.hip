@@ -123,6 +123,7 @@ struct ItemPool
 // The whole scene is resident in LDS; waves never wait for each other.
 struct WaveEnv
 {
+  static constexpr uint32_t kFilterUnroll = 2;
   const TraceArgs & A;
   const f4 * filt;       // LDS: n_padded filter records
   const f4 * cam;        // LDS: n_padded camera-table records
@@ -210,6 +211,7 @@ struct WaveEnv
 // pass, so all of its waves take the same trips and every loop decision is block-wide.
 struct BlockEnv
 {
+  static constexpr uint32_t kFilterUnroll = 4;  // almost all of this path's time is the filter: three waves, wider loop
   const TraceArgs & A;
   f4 * tile;              // LDS: kTileSpheres entries
   const float * jitter;   // LDS: RT_JITTER_FLOATS
@@ -249,6 +251,7 @@ struct BlockEnv
 // wait for each other.  The tile functions are unused.
 struct GridEnv
 {
+  static constexpr uint32_t kFilterUnroll = 2;
   const TraceArgs & A;
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ItemPool pool;
@@ -319,7 +322,7 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
 template <bool kTiled, bool kForward>
-__global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel(TraceArgs A)
+__global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   f4 * stack = reinterpret_cast<f4 *>(lds_raw);                    // [RT_MAX_DEPTH][kBlock]

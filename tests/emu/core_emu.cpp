@@ -10,6 +10,7 @@ namespace
 {
 struct HostEnv
 {
+  static constexpr uint32_t kFilterUnroll = 4;
   const rtc::TraceArgs & A;
   uint32_t total;
   uint32_t tile_size;
