@@ -96,8 +96,10 @@ typedef struct
   uint64_t ray_queries;    /* nearest-hit + shadow queries the algorithm asks for, each against all spheres */
   uint64_t hit_queries;    /* queries that found a hit */
   uint64_t shaded_bounces; /* hits that ran direct light + specular */
-  uint64_t sphere_tests;   /* ray-sphere filter tests executed (every traced ray against every sphere) */
-  uint64_t exact_tests;    /* candidates the filter let through, intersected exactly */
+  uint64_t sphere_tests;   /* ray-sphere filter tests executed: every shadow and scattered ray against every sphere;
+                              primary rays once per sample, or once per column for scenes of at most 64 spheres;
+                              0 on the grid path */
+  uint64_t exact_tests;    /* exact intersections run: the candidates the filter (or the grid walk) let through */
   uint64_t lane_trips;     /* trips round the kernel's main loop, summed over lanes (busy or idle) */
   uint64_t lane_rounds;    /* primary-ray rounds inside those trips, summed over lanes (busy or idle) */
   float kernel_ms;         /* device time of the trace kernel, HIP events on the launch stream; 0 if not measured */

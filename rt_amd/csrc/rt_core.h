@@ -53,7 +53,6 @@ constexpr uint32_t RT_MAX_DEPTH = 10;  // demos/demo_frame_cpu.cpp:10
 constexpr float RT_EPS = 1e-5f;        // ray_tracing/types.hpp:9
 constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
-constexpr uint32_t RT_PAD = 1;         // sphere arrays are padded to a multiple of this with never-hit entries
 constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
 constexpr uint32_t RT_UNROLL = 2;      // camera-table entries per trip of the primary filter's main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
@@ -225,8 +224,8 @@ struct TraceArgs
                                // f0^2, 1 / refraction), (r^2, 4 r^2, metal emissivity, 0) with r = max(roughness, 0.03)
   const f4 * lights;           // n_lights x 2: (direction xyz, 0), (colour rgb, 0)
   const float * jitter_tab;    // RT_JITTER_FLOATS, see jitter_ball
-  uint32_t n_spheres, n_padded, n_materials, n_lights;
-  uint32_t tile_size;          // filter records staged per tile when the scene is not resident (multiple of RT_PAD)
+  uint32_t n_spheres, n_padded, n_materials, n_lights;  // n_padded: records in the sphere arrays (= n_spheres)
+  uint32_t tile_size;          // filter records staged per tile when the scene is not resident 
   // camera, precomputed on the host exactly as Frame::ForEachRayImpl does (ray_tracing/frame.cpp:33-41)
   f3 cam_pos, cam_dir, cam_right, cam_up, background;
   float znear, zfar, dw, dh, cell_x, cell_y;
@@ -573,7 +572,7 @@ RT_FN uint32_t chunk_candidates(uint32_t rejected, uint32_t count)
   return ~rejected & valid;
 }
 
-// Filter of one ray against `count` (<= RT_CHUNK, a multiple of RT_PAD) camera-table entries
+// Filter of one ray against `count` (<= RT_CHUNK) camera-table entries
 // (centre - camera, bound).
 RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
 {
@@ -606,7 +605,7 @@ RT_FN void filter_sphere_6(f4 s, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask
     mask[r] = push_sign(mask[r], hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
 }
 
-// Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK, a multiple of RT_PAD) spheres.
+// Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK) spheres.
 template <uint32_t kUnroll>
 RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask)[RT_RAYS])
 {

@@ -569,8 +569,8 @@ uint32_t forced_tile()
   const char * v = std::getenv("RT_HIP_FORCE_TILE");
   if (v == nullptr)
     return 0u;
-  uint32_t const n = (uint32_t)std::strtoul(v, nullptr, 10) / RT_PAD * RT_PAD;
-  return std::min(std::max(n, RT_PAD), kTileSpheres);
+  uint32_t const n = (uint32_t)std::strtoul(v, nullptr, 10);
+  return std::min(std::max(n, 1u), kTileSpheres);
 }
 
 bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }

@@ -215,8 +215,8 @@ inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
 // Scene records in the layout the kernel reads.
 struct FlatScene
 {
-  std::vector<f4> spheres;           // (cx, cy, cz, r*r), padded to a multiple of RT_PAD
-  std::vector<f4> filter;            // (cx, cy, cz, r*r widened by the filter margin), padded likewise
+  std::vector<f4> spheres;           // (cx, cy, cz, r*r)
+  std::vector<f4> filter;            // (cx, cy, cz, r*r widened by the filter margin)
   std::vector<uint32_t> sphere_mat;  // material index per sphere
   std::vector<f4> materials;         // RT_MAT_RECORDS per material
   std::vector<f4> lights;            // 2 per light
@@ -236,10 +236,8 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
                           const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                           FlatScene & out)
 {
-  uint32_t const padded = (n + RT_PAD - 1u) / RT_PAD * RT_PAD;
-  // Padding entries can never pass the filter: a hugely negative r^2 puts every origin far outside.
-  out.spheres.assign(padded, mk4(0.0f, 0.0f, 0.0f, -1e30f));
-  out.filter.assign(padded, mk4(0.0f, 0.0f, 0.0f, -1e30f));
+  out.spheres.resize(n);
+  out.filter.resize(n);
   out.sphere_mat.assign(material_index, material_index + n);
   for (uint32_t i = 0; i < n; ++i)
   {
