@@ -46,8 +46,20 @@ def profiled_traffic(workload_key):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene, width, height, samples_in_row):
-    """The oracle (a port of the reference's CPU path) on a bounded sample of the workload."""
+    """The oracle (a port of the reference's CPU path) on a bounded sample of the workload: all the threads
+    this process may use (at most 16), and one thread on a sixteenth of that sample."""
     from oracle import oracle_ffi  # checker; used here as the reported CPU baseline only
 
     threads = min(os.cpu_count() or 1, 16)
@@ -55,6 +67,10 @@ def cpu_baseline(scene, width, height, samples_in_row):
     t0 = time.perf_counter()
     _, st = oracle_ffi.render(scene, p, threads)
     dt = time.perf_counter() - t0
+    p1 = ffi.params(max(width // 4, 16), max(height // 4, 16), samples_in_row, seed=1)
+    t0 = time.perf_counter()
+    _, st1 = oracle_ffi.render(scene, p1, 1)
+    dt1 = time.perf_counter() - t0
     return {
         "value": round(st.samples / dt / 1e6, 3),
         "unit": "Msamples/s",
@@ -62,6 +78,11 @@ def cpu_baseline(scene, width, height, samples_in_row):
         "kind": "port",
         "sample": "same scene and camera at %dx%d, %dx%d samples per pixel (%.1f Msamples, %.1f s)"
                   % (width, height, samples_in_row, samples_in_row, st.samples / 1e6, dt),
+        "value_1_thread": round(st1.samples / dt1 / 1e6, 3),
+        "sample_1_thread": "%dx%d, %dx%d samples per pixel (%.1f Msamples, %.1f s)"
+                           % (p1.width, p1.height, samples_in_row, samples_in_row, st1.samples / 1e6, dt1),
+        "cpu_model": cpu_model(),
+        "host_cpus": os.cpu_count(),
     }
 
 
