@@ -131,3 +131,33 @@ def test_cli_renders_a_scene_file(hip, ffi, scenes, tmp_path):
     bad.write_text("rt-scene 1\nsphere 0 0 0 1 nope\n")
     res = subprocess.run([cli, "--scene", str(bad)] + common, capture_output=True, text=True, timeout=120)
     assert res.returncode == 1 and "unknown material" in res.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_device_path_slices_reduce_to_the_frame(hip, ffi, scenes, world):
+    """What bench.py does on several GPUs, replayed on one: every rank's slice traced into its own planes with
+    rt_hip_trace_device, the planes summed (the RCCL reduce), the sum resolved."""
+    import torch
+
+    from rt_amd import sharding
+
+    scene = scenes(1)
+    w, h, s = 160, 90, 4
+    full = ffi.params(w, h, s, seed=4)
+    ref, rs = hip.render(scene, full)
+    total = torch.zeros(3 * w * h, dtype=torch.float32, device="cuda")
+    stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+    samples = 0
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(world):
+        p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=4), rank, world)
+        planes = torch.full((3 * w * h,), float("nan"), dtype=torch.float32, device="cuda")  # must be overwritten
+        hip.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
+        torch.cuda.synchronize()
+        total += planes
+        samples += int(stats[0])
+    rgb = torch.empty(w * h * 3, dtype=torch.float32, device="cuda")
+    hip.resolve_device(total.data_ptr(), rgb.data_ptr(), full, stream)
+    torch.cuda.synchronize()
+    assert samples == rs.samples
+    np.testing.assert_allclose(rgb.cpu().numpy().reshape(h, w, 3), ref, rtol=2e-6, atol=1e-7)
