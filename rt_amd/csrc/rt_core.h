@@ -1066,15 +1066,6 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     float a[RT_RAYS];
     uint32_t rays_on = 0;
     float w[RT_LIGHT_SAMPLES];
-#pragma unroll
-    for (int r = 0; r < RT_RAYS; ++r)
-    {
-      dir[r] = mk3(0.0f, 0.0f, 1.0f);
-      a[r] = 1.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
-      w[j] = 0.0f;
 
     if (L.alive && L.has_hit)
     {
@@ -1135,73 +1126,63 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 
     bool const in_pass = L.alive && L.shading;
     RT_REGION(cnt, 5);
-    if (in_pass)
+    // The ray set-up below runs for every lane, in a pass or not: lanes that are not compute throw-away rays
+    // from their stale (always initialised) state, and rays_on keeps those rays out of the trace.  That is
+    // cheaper than a divergent region whose results must be merged with defaults.
+    bool const lit = in_pass && L.li < A.n_lights;
     {
-      if (L.li < A.n_lights)
+      uint32_t const li_c = (L.li < A.n_lights) ? L.li : 0u;
+      f3 to_light = mk3(0.0f, 1.0f, 0.0f);
+      if (A.n_lights != 0u)
       {
-        f4 const l0 = env.light(L.li, 0u);
-        f3 const to_light = mk3(-l0.x, -l0.y, -l0.z);
-        f3 jit[RT_LIGHT_SAMPLES];
+        f4 const l0 = env.light(li_c, 0u);
+        to_light = mk3(-l0.x, -l0.y, -l0.z);
+      }
+      if (deterministic)
+      {
+        // No jitter: the five shadow rays are one ray, normalised exactly as the reference does
+        // (ray_tracing/directional_light.cpp:20), so that a shadow edge never falls between two roundings.
+        f3 const rd = normalize3(to_light);
+        float const aa = dot3(rd, rd);
+        float const ww = maxf(0.0f, dot3(rd, L.hn));
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
-          jit[j] = mk3(0.0f, 0.0f, 0.0f);
-        if (!deterministic)
         {
-          // 15 cells of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
-          u4 p0 = L.shadow_words;
-          if (L.li != 0u)
-            p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
-          uint32_t const wd[4] = {p0.x, p0.y, p0.z, p0.w};
-#pragma unroll
-          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
-          {
-            uint32_t k[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-            {
-              int const h = 3 * j + q;
-              k[q] = (wd[h >> 2] >> (8 * (h & 3))) & 0xFFu;
-            }
-            jit[j] = jitter_ball(env.jitter_table(), k[0], k[1], k[2]);
-          }
+          dir[j] = rd;
+          a[j] = aa;
+          w[j] = ww;
         }
-        if (deterministic)
-        {
-          // No jitter: the five shadow rays are one ray, normalised exactly as the reference does
-          // (ray_tracing/directional_light.cpp:20), so that a shadow edge never falls between two roundings.
-          f3 const rd = normalize3(to_light);
-          float const aa = dot3(rd, rd);
-          float const ww = maxf(0.0f, dot3(rd, L.hn));
-#pragma unroll
-          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
-          {
-            dir[j] = rd;
-            a[j] = aa;
-            w[j] = ww;
-          }
-        }
-        else
-        {
-#pragma unroll
-          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
-          {
-            // jittered directions need no exact rounding: fused multiply-adds and the hardware rsqrt
-            f3 const v = to_light + jit[j];
-            float const inv = hw_rsq(fdot3(v, v));
-            f3 const rd = v * inv;
-            dir[j] = rd;
-            a[j] = fdot3(rd, rd);
-            w[j] = hw_max(0.0f, fdot3(rd, L.hn));
-          }
-        }
-        rays_on |= (1u << RT_LIGHT_SAMPLES) - 1u;
       }
-      if (L.li == 0)
+      else
       {
-        dir[RT_RAYS - 1] = L.sdir;
-        a[RT_RAYS - 1] = L.s_a;
-        rays_on |= 1u << (RT_RAYS - 1);
+        // 15 cells of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
+        u4 p0 = L.shadow_words;
+        if (lit && L.li != 0u)
+          p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
+        uint32_t const wd[4] = {p0.x, p0.y, p0.z, p0.w};
+#pragma unroll
+        for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+        {
+          uint32_t k[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+          {
+            int const h = 3 * j + q;
+            k[q] = (wd[h >> 2] >> (8 * (h & 3))) & 0xFFu;
+          }
+          // jittered directions need no exact rounding: fused multiply-adds and the hardware rsqrt
+          f3 const v = to_light + jitter_ball(env.jitter_table(), k[0], k[1], k[2]);
+          float const inv = hw_rsq(fdot3(v, v));
+          f3 const rd = v * inv;
+          dir[j] = rd;
+          a[j] = fdot3(rd, rd);
+          w[j] = hw_max(0.0f, fdot3(rd, L.hn));
+        }
       }
+      rays_on = lit ? ((1u << RT_LIGHT_SAMPLES) - 1u) : 0u;
+      dir[RT_RAYS - 1] = L.sdir;
+      a[RT_RAYS - 1] = L.s_a;
+      rays_on |= (in_pass && L.li == 0u) ? (1u << (RT_RAYS - 1)) : 0u;
     }
 
     float near_t;
@@ -1226,7 +1207,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           color = color + (blocked ? tint : lcol) * w[j];
           cnt.hits += blocked ? 1u : 0u;
         }
-        L.diffuse = L.diffuse + color / (float)RT_LIGHT_SAMPLES;
+        L.diffuse = L.diffuse + color * (1.0f / (float)RT_LIGHT_SAMPLES);
         cnt.queries += RT_LIGHT_SAMPLES;
       }
       if (L.li == 0)
