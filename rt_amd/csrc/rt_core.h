@@ -318,6 +318,20 @@ RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float 
   return true;
 }
 
+// The same test without early exits (a negative discriminant makes the square root a NaN and every
+// comparison false), for resolving two candidates side by side.  Same operations, same results.
+RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out)
+{
+  f3 const d = o - mk3(s.x, s.y, s.z);
+  float const b = 2.0f * dot3(d, dir);
+  float const c = dot3(d, d) - s.w;
+  float const disc = b * b - 4 * a * c;
+  float const sq = sqrtf(disc);
+  float const t = (-b - sq) / (2.0f * a);
+  t_out = t;
+  return disc >= 0.0f && t >= tmin && t <= tmax;
+}
+
 // Per-lane state.
 struct Lane
 {
@@ -894,38 +908,37 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       }
       if (!env.any_wave(any_mask != 0u))
         continue;
-      // Shadow rays: existence of a hit in [0.001, 1000] is all TraceLight uses.
+      // Candidates are resolved two rays at a time, without branches inside an iteration: the two exact
+      // intersections are independent chains of dependent instructions (IEEE sqrt and division) and interleave.
+      // Shadow rays: existence of a hit in [0.001, 1000] is all TraceLight uses.  Scattered ray (the last one):
+      // nearest hit; secondary hits start at 0.001 (demos/demo_frame_cpu.cpp:53).
+      uint32_t const base = tile_base + c0;
 #pragma unroll
-      for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
+      for (int r = 0; r < RT_RAYS; r += 2)
       {
-        while (env.any_wave(mask[r] != 0u))
+        while (env.any_wave((mask[r] | mask[r + 1]) != 0u))
         {
-          if (mask[r] != 0u)
+          bool const h0 = mask[r] != 0u, h1 = mask[r + 1] != 0u;
+          uint32_t m0 = h0 ? mask[r] : 1u, m1 = h1 ? mask[r + 1] : 1u;
+          int const i0 = (int)(base + pop_candidate(m0, count)), i1 = (int)(base + pop_candidate(m1, count));
+          float t0, t1;
+          bool const hit0 = exact_hit_flat(o, dir[r], a[r], env.sphere(i0), 0.001f, 1000.0f, t0) && h0;
+          bool const last = (r + 1 == RT_RAYS - 1);
+          bool const hit1 = exact_hit_flat(o, dir[r + 1], a[r + 1], env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1) && h1;
+          cnt.exact_tests += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
+          live = hit0 ? (live & ~(1u << r)) : live;
+          mask[r] = (hit0 || !h0) ? 0u : m0;
+          if (last)
           {
-            int const i = (int)(tile_base + c0 + pop_candidate(mask[r], count));
-            float t;
-            cnt.exact_tests += 1;
-            if (exact_hit(o, dir[r], a[r], env.sphere(i), 0.001f, 1000.0f, t))
-            {
-              live &= ~(1u << r);
-              mask[r] = 0u;
-            }
+            bool const nearer = hit1 && (near_i < 0 || t1 < near_t);
+            near_i = nearer ? i1 : near_i;
+            near_t = nearer ? t1 : near_t;
+            mask[r + 1] = h1 ? m1 : 0u;
           }
-        }
-      }
-      // Scattered ray: nearest hit; secondary hits start at 0.001 (demos/demo_frame_cpu.cpp:53).
-      while (env.any_wave(mask[RT_RAYS - 1] != 0u))
-      {
-        if (mask[RT_RAYS - 1] != 0u)
-        {
-          int const i = (int)(tile_base + c0 + pop_candidate(mask[RT_RAYS - 1], count));
-          float t;
-          cnt.exact_tests += 1;
-          if (exact_hit(o, dir[RT_RAYS - 1], a[RT_RAYS - 1], env.sphere(i), 0.001f, A.zfar, t) &&
-              (near_i < 0 || t < near_t))
+          else
           {
-            near_i = i;
-            near_t = t;
+            live = hit1 ? (live & ~(1u << (r + 1))) : live;
+            mask[r + 1] = (hit1 || !h1) ? 0u : m1;
           }
         }
       }
