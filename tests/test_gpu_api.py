@@ -161,3 +161,28 @@ def test_device_path_slices_reduce_to_the_frame(hip, ffi, scenes, world):
     torch.cuda.synchronize()
     assert samples == rs.samples
     np.testing.assert_allclose(rgb.cpu().numpy().reshape(h, w, 3), ref, rtol=2e-6, atol=1e-7)
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
+    """bench.py on a small frame: one JSON line on stdout with the fields the driver reads."""
+    import sys
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "180", "--samples", "4"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["unit"] == "Msamples/s" and out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["higher_is_better"] is True
+    assert "workload" in out["config"] and "model" not in out["config"]
+    assert out["value"] == pytest.approx(320 * 180 * 16 / (out["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    roof = out["roofline"]
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3) and roof["unit"] == "TFLOP/s"
+    assert roof["kernel_ms"] > 0 and roof["traffic"] is None  # traffic is only known for the profiled workload
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
