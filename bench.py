@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--spheres", type=int, default=10000, help="sphere count of demo 3")
     ap.add_argument("--grid", action="store_true", help="rays walk the scene's uniform grid (scenes of 64+ spheres)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
+                         "collectives run over gloo on host copies (timings are not meaningful)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,12 +113,17 @@ def main():
         if not distributed and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if distributed:
         import torch.distributed as dist  # nccl == RCCL on ROCm
 
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     renderer = ffi.HipRenderer(local_rank)  # raises if librt_hip.so or the GPU is missing: no fallback
     scene = ffi.Scene.demo(args.demo, 1, args.spheres)
@@ -133,7 +141,12 @@ def main():
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         renderer.trace_device(scene, p, planes.data_ptr(), d_stats.data_ptr(), stream)
-        sharding.reduce_to_root(dist, planes, world)
+        if args.rehearse and distributed:
+            host = planes.cpu()
+            sharding.reduce_to_root(dist, host, world)
+            planes.copy_(host)
+        else:
+            sharding.reduce_to_root(dist, planes, world)
         if rank == 0:
             renderer.resolve_device(planes.data_ptr(), rgb.data_ptr(), full, stream)
 
@@ -151,13 +164,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # counters of this rank's last trace, summed over ranks
     counters = d_stats[:8].clone()
     if distributed:
+        if args.rehearse:
+            counters = counters.cpu()
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     names = ["samples", "ray_queries", "hit_queries", "shaded_bounces", "sphere_tests", "exact_tests", "lane_trips",
              "lane_rounds"]
