@@ -186,3 +186,27 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert roof["kernel_ms"] > 0 and roof["traffic"] is None  # traffic is only known for the profiled workload
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu(tmp_path):
+    """The multi-rank flow of bench.py (slices, reduce to rank 0, resolve, counters, one JSON line from rank 0)
+    with two processes that share this GPU and reduce over gloo: same frame as one rank."""
+    import sys
+
+    common = ["--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--samples", "4",
+              "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert one.returncode == 0, one.stdout + one.stderr
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--rehearse"] + common,
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert two.returncode == 0, two.stdout + two.stderr
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and "cpu_baseline" not in b
+    assert b["mean_radiance"] == pytest.approx(a["mean_radiance"], abs=2e-5)
+    assert b["ray_queries_per_sample"] == pytest.approx(a["ray_queries_per_sample"], abs=1e-3)
