@@ -210,3 +210,19 @@ def test_two_rank_bench_rehearsal_on_one_gpu(tmp_path):
     assert b["n_gpus"] == 2 and "cpu_baseline" not in b
     assert b["mean_radiance"] == pytest.approx(a["mean_radiance"], abs=2e-5)
     assert b["ray_queries_per_sample"] == pytest.approx(a["ray_queries_per_sample"], abs=1e-3)
+
+
+def test_oversized_frames_are_refused_before_anything_is_allocated(hip, ffi, scenes):
+    lib = hip.lib
+    scene = scenes(1)
+    handle = hip.upload(scene)
+    job = C.c_void_p()
+    for bad, word in ((ffi.params(8, 8, 5000), b"4096"), (ffi.params(65536, 65536, 1), b"2^30"),
+                      (ffi.params(32768, 32768, 4), b"0xF0000000")):
+        assert lib.rt_hip_trace_async(handle, C.byref(scene.camera), C.byref(bad), C.byref(job)) == 1
+        assert word in lib.rt_hip_last_error(), lib.rt_hip_last_error()
+        assert not job.value
+    # the largest supersampling the interface takes, on a tiny frame
+    p = ffi.params(2, 2, 4096, seed=1)
+    out, st = hip.render(scene, p)
+    assert st.samples == 4 * 4096 * 4096 and np.isfinite(out).all()

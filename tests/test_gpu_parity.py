@@ -1,6 +1,6 @@
 """Parity of the HIP backend with the oracle, through the C ABI, on a real MI355X.
 
-Tolerances (from the build's north star):
+Tolerances:
   * deterministic mode (no stochastic scattering): every pixel within 1e-4 relative (floor 1e-3 absolute
     radiance in the denominator) of the CPU path;
   * stochastic mode, same Philox streams on both sides: mean absolute error below 1e-4 and at most 0.5 % of
