@@ -185,6 +185,18 @@ def main():
     kernel_flop = algorithmic_flop(k, scene.sphere_count)
     achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
 
+    # the resolve pass alone (HBM-bound: reads 12 B and writes 12 B per pixel), events on its launch stream
+    resolve_ms = None
+    if rank == 0:
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(10):
+            renderer.resolve_device(planes.data_ptr(), rgb.data_ptr(), full, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        resolve_ms = e0.elapsed_time(e1) / 10.0
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_samples = w * h * s * s
@@ -230,6 +242,14 @@ def main():
                     k["sphere_tests"] / max(k["ray_queries"] * scene.sphere_count, 1), 4),
                 "lane_utilisation": round(k["shaded_bounces"] / max(k["lane_trips"], 1), 4),
             },
+        }
+        out["resolve_pass"] = {
+            "bound": "hbm",
+            "bytes": 24 * w * h,
+            "ms": round(resolve_ms, 4),
+            "achieved": round(24.0 * w * h / (resolve_ms * 1e-3) / 1e9, 1),
+            "peak": 8000.0,
+            "unit": "GB/s",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, max(w // 2, 16), max(h // 2, 16), s)
