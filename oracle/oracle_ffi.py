@@ -130,3 +130,49 @@ def render(scene, p, threads=None):
     if rc != 0:
         raise RuntimeError("orc_render failed with %d" % rc)
     return rgb, stats
+
+
+_FRAME_PATH = os.path.join(_HERE, "liboracle_frame.so")
+_frame_lib = None
+
+
+def load_frame():
+    """liboracle_frame.so: the oracle behind the Frame plug-in interface (oracle/frame_cpu.cpp)."""
+    global _frame_lib
+    if _frame_lib is None:
+        load()
+        if not os.path.exists(_FRAME_PATH):
+            build()
+        lib = C.CDLL(_FRAME_PATH)
+        lib.orc_frame_render_demo.restype = C.c_int
+        lib.orc_frame_render_demo.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                              C.POINTER(OrcStats)]
+        lib.orc_frame_render_scene_file.restype = C.c_int
+        lib.orc_frame_render_scene_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
+        _frame_lib = lib
+    return _frame_lib
+
+
+def render_demo_through_frame(index, p, scene_seed=1, spheres=10000, threads=None):
+    """A demo built around the CPU checker's Frame (DemoFrameCPU), driven as the reference's App drives one."""
+    lib = load_frame()
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 16)
+    rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    stats = OrcStats()
+    rc = lib.orc_frame_render_demo(index, scene_seed, spheres, C.byref(p), threads, rgb.ctypes.data, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("orc_frame_render_demo failed with %d" % rc)
+    return rgb, stats
+
+
+def render_scene_file_through_frame(path, p, threads=None):
+    lib = load_frame()
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 16)
+    rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    stats = OrcStats()
+    rc = lib.orc_frame_render_scene_file(os.fsencode(path), C.byref(p), threads, rgb.ctypes.data, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("orc_frame_render_scene_file failed with %d" % rc)
+    return rgb, stats

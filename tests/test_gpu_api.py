@@ -226,3 +226,15 @@ def test_oversized_frames_are_refused_before_anything_is_allocated(hip, ffi, sce
     p = ffi.params(2, 2, 4096, seed=1)
     out, st = hip.render(scene, p)
     assert st.samples == 4 * 4096 * 4096 and np.isfinite(out).all()
+
+
+@pytest.mark.parametrize("demo", [1, 2])
+def test_same_demo_around_either_frame(oracle, ffi, demo):
+    """The drop-in, end to end: one scene builder (demo::PrettySpheres / GlassSpheres), once around DemoFrameHIP and
+    once around the CPU checker's DemoFrameCPU, both driven through the Frame virtuals only."""
+    p = ffi.params(128, 96, 2, flags=ffi.FLAG_DETERMINISTIC)
+    hip_rgb, hs = ffi.render_demo(demo, p, scene_seed=1)
+    cpu_rgb, cs = oracle.render_demo_through_frame(demo, p, scene_seed=1)
+    err = np.abs(cpu_rgb - hip_rgb) / np.maximum(np.abs(cpu_rgb), 1e-3)
+    assert err.max() < 1e-4
+    assert (hs.samples, hs.ray_queries, hs.hit_queries) == (cs.samples, cs.ray_queries, cs.hit_queries)

@@ -139,3 +139,27 @@ def test_all_hits_of_a_collection_are_sorted_and_agree_with_nearest(oracle, scen
     assert lib.orc_trace_all(C.byref(osc), C.byref(o), C.byref(d), 0.001, 1000.0, small, 2) == total
     for i in range(min(total, 2)):
         assert small[i].t == out[i].t and small[i].sphere == out[i].sphere
+
+
+@pytest.mark.parametrize("demo", [1, 2, 3])
+def test_frame_interface_on_the_checker_equals_the_flat_call(oracle, ffi, scenes, demo):
+    """DemoFrameCPU (oracle/frame_cpu.cpp) built into the same demo::Demo the HIP frame is built into renders
+    what orc_render renders from the flattened arrays: the Frame seam adds nothing of its own."""
+    p = ffi.params(48, 36, 2, seed=3)
+    via_frame, fs = oracle.render_demo_through_frame(demo, p, scene_seed=1, spheres=200, threads=3)
+    flat, rs = oracle.render(scenes(demo, 1, 200), p, 3)
+    np.testing.assert_array_equal(via_frame, flat)
+    assert fs.as_dict() == rs.as_dict()
+
+
+def test_scene_file_through_the_checkers_frame(oracle, ffi, scenes, tmp_path):
+    scene = scenes(1)
+    path = tmp_path / "pretty.rtscene"
+    scene.save(str(path))
+    p = ffi.params(40, 30, 2, flags=ffi.FLAG_DETERMINISTIC, max_depth=1)
+    a, sa = oracle.render_scene_file_through_frame(str(path), p, threads=2)
+    b, sb = oracle.render(scene, p, 2)
+    # the camera direction is normalised again on load (an ulp): every ray moves by ~1e-7, an edge sample may flip
+    close = np.abs(a - b).max(axis=2) <= 1e-5 * np.maximum(np.abs(b).max(axis=2), 1e-3)
+    assert close.mean() > 0.99
+    assert sa.samples == sb.samples
