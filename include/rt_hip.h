@@ -125,7 +125,7 @@ int rt_hip_device_info(int * compute_units, int * clock_khz, char * name, size_t
 /* Uploads a flattened scene once; replaces the per-trace cudaMalloc+cudaMemcpy of spheres, materials and
  * lights in ray_tracing_cuda::RayTrace (rt_cuda/rt_cuda.cu:186-223).  centers_radii = sphere_count x
  * {cx, cy, cz, radius} (CudaSphere's centre and radius), material_index = sphere_count indices into
- * materials.  The caller keeps its arrays. */
+ * materials; centres and radii must be finite (RT_HIP_ERR_INVALID otherwise).  The caller keeps its arrays. */
 int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_index, uint32_t sphere_count,
                         const rt_hip_material * materials, uint32_t material_count,
                         const rt_hip_light * lights, uint32_t light_count, rt_hip_scene ** out_scene);

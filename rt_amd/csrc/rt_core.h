@@ -318,8 +318,8 @@ RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float 
   return true;
 }
 
-// The same test without early exits (a negative discriminant makes the square root a NaN and every
-// comparison false), for resolving two candidates side by side.  Same operations, same results.
+// The same test without early exits, for resolving two candidates side by side.  Same operations, same
+// results (a negative discriminant is rejected whatever its square root turns into).
 RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out)
 {
   f3 const d = o - mk3(s.x, s.y, s.z);
@@ -329,7 +329,7 @@ RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, f
   float const sq = sqrtf(disc);
   float const t = (-b - sq) / (2.0f * a);
   t_out = t;
-  return disc >= 0.0f && t >= tmin && t <= tmax;
+  return !(disc < 0.0f) && !(t < tmin || t > tmax);  // the reference's two rejections, NaNs included
 }
 
 // Per-lane state.

@@ -954,6 +954,11 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   for (uint32_t i = 0; i < sphere_count; ++i)
     if (material_index[i] >= material_count)
       return fail(RT_HIP_ERR_INVALID, "material index out of range");
+  // The reference's range test lets a NaN distance through (ray_tracing/sphere.cpp:75), so a sphere with a NaN
+  // in it "hits" wherever nothing nearer does; that is refused here rather than reproduced.
+  for (size_t i = 0; i < (size_t)sphere_count * 4u; ++i)
+    if (!std::isfinite(centers_radii[i]))
+      return fail(RT_HIP_ERR_INVALID, "non-finite sphere centre or radius");
   for (uint32_t i = 0; i < material_count; ++i)
     if (materials[i].type > RT_HIP_MATERIAL_GLASS)
       return fail(RT_HIP_ERR_INVALID, "unknown material type");

@@ -119,7 +119,12 @@ inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
     return;
   std::vector<float> radii(n);
   for (uint32_t i = 0; i < n; ++i)
+  {
     radii[i] = std::fabs(centers_radii[4u * i + 3u]);
+    for (uint32_t k = 0; k < 4u; ++k)
+      if (!std::isfinite(centers_radii[4u * i + k]))
+        return;  // no grid for a scene with non-finite spheres: such a scene is traced sphere by sphere
+  }
   std::vector<float> sorted(radii);
   std::nth_element(sorted.begin(), sorted.begin() + n / 2u, sorted.end());
   double const typical = std::max((double)sorted[n / 2u], 1e-6);
@@ -166,6 +171,8 @@ inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
   }
   s_lo = std::max(s_lo, std::max({ext[0], ext[1], ext[2]}) / 1024.0);  // at most 1024 cells along an axis
   g.cell = (float)s_lo;
+  if (!(g.cell > 0.0f) || !std::isfinite(g.cell))
+    return;
   size_t cells = 1;
   for (int k = 0; k < 3; ++k)
   {

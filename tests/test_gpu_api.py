@@ -180,9 +180,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert out["unit"] == "Msamples/s" and out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
     assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["higher_is_better"] is True
     assert "workload" in out["config"] and "model" not in out["config"]
-    assert out["value"] == pytest.approx(320 * 180 * 16 / (out["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    assert out["value"] == pytest.approx(320 * 180 * 16 / (out["ms_per_step"] * 1e-3) / 1e6, rel=5e-3)
     roof = out["roofline"]
-    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3) and roof["unit"] == "TFLOP/s"
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=2e-4) and roof["unit"] == "TFLOP/s"
     assert roof["kernel_ms"] > 0 and roof["traffic"] is None  # traffic is only known for the profiled workload
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0

@@ -211,3 +211,14 @@ def test_grid_flag_is_ignored_for_small_scenes(hip, ffi, scenes):
     b, sb = hip.render(scene, ffi.params(64, 48, 2, seed=2, flags=ffi.FLAG_GRID))
     np.testing.assert_array_equal(a, b)
     assert sa.sphere_tests == sb.sphere_tests > 0
+
+
+def test_non_finite_spheres_are_refused(hip, ffi):
+    """Sphere::TraceNearest rejects with `t < tmin || t > tmax`, which a NaN distance passes, so in the reference
+    a sphere with a NaN in it "hits" wherever nothing nearer does.  The backend refuses such scenes instead."""
+    mats = [(0, (0.7, 0.6, 0.5), 0.7, 0.0)]
+    for bad in ((float("nan"), 0.0, 2.0, 0.5, 0), (0.0, 0.5, 3.0, float("inf"), 0)):
+        scene = ffi.Scene.build([(0.0, -1001.0, 0.0, 1000.0, 0), bad], mats, [((0.0, -1.0, 0.0), (1.0, 1.0, 1.0))],
+                                dict(position=(0.0, 0.5, -3.0), direction=(0.0, -0.2, 1.0)))
+        with pytest.raises(ffi.HipError, match="non-finite sphere"):
+            hip.render(scene, ffi.params(16, 16, 1))
