@@ -1212,15 +1212,19 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         f3 const lcol = mk3(l1.x, l1.y, l1.z);
         // An occluded sample is tinted by the shaded surface's own material.
         f3 const tint = mix3(L.m_albedo, lcol, 0.75f) * (L.m_refraction * 0.75f);
-        f3 color = mk3(0.0f, 0.0f, 0.0f);
+        // sum of (blocked ? tint : colour) * w_j, gathered as two weights (a colour, not geometry: the last
+        // bits may differ from adding sample by sample)
+        float w_blocked = 0.0f, w_open = 0.0f;
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
         {
           bool const blocked = ((occluded >> j) & 1u) != 0u;
-          color = color + (blocked ? tint : lcol) * w[j];
-          cnt.hits += blocked ? 1u : 0u;
+          w_blocked += blocked ? w[j] : 0.0f;
+          w_open += blocked ? 0.0f : w[j];
         }
-        L.diffuse = L.diffuse + color * (1.0f / (float)RT_LIGHT_SAMPLES);
+        cnt.hits += (uint32_t)__builtin_popcount(occluded);
+        float const fifth = 1.0f / (float)RT_LIGHT_SAMPLES;
+        L.diffuse = L.diffuse + (tint * (w_blocked * fifth) + lcol * (w_open * fifth));
         cnt.queries += RT_LIGHT_SAMPLES;
       }
       if (L.li == 0)
