@@ -170,3 +170,20 @@ def test_deterministic_frames_are_pinned(oracle, ffi, scenes, name, demo, sphere
     p = ffi.params(64, 48, 2, flags=ffi.FLAG_DETERMINISTIC, seed=1, max_depth=depth)
     rgb, _ = oracle.render(scenes(demo, 1, spheres), p, 3)
     np.testing.assert_array_equal(rgb, golden)
+
+
+@pytest.mark.parametrize("demo,spheres", [(1, 0), (2, 0), (3, 120)])
+def test_depth_one_frames_against_an_independent_numpy_statement(oracle, ffi, scenes, demo, spheres):
+    """The oracle's D1 frame (primary hit + direct light + specular, no random draws) against a float64 numpy
+    rendering written separately from the reference's text (tests/numpy_d1.py).  float32 against float64: a few
+    1e-6 apart, except where a sample sits on an edge and the two roundings disagree about a hit."""
+    import numpy_d1
+
+    scene = scenes(demo, 1, spheres or 10000)
+    w, h, s = 48, 36, 2
+    ref = numpy_d1.render_d1(scene, w, h, s)
+    out, _ = oracle.render(scene, ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC, max_depth=1), 4)
+    err = np.abs(out - ref).max(axis=2) / np.maximum(np.abs(ref).max(axis=2), 1e-3)
+    assert (err > 1e-4).mean() < 0.01, "pixels off: %d" % int((err > 1e-4).sum())
+    assert np.median(err) < 1e-5
+    assert abs(float(out.mean()) - float(ref.mean())) < 1e-3
