@@ -101,3 +101,125 @@ def render_d1(scene, width, height, s_row):
         shaded = 0.5 * (albedo + diffuse + spec)
         colour[hit] = np.where(absorbed[:, None], 0.5 * background, shaded)
     return colour.reshape(height, width, s_row * s_row, 3).mean(axis=2)
+
+
+def _light_terms(scene, spheres, p, d, n, albedo, rough, refr):
+    """TraceLight with un-jittered rays + GetSpecular, summed over the lights, for hits (p, n) seen along d."""
+    diffuse = np.zeros_like(albedo)
+    spec = np.zeros_like(albedo)
+    for k in range(scene.light_count):
+        ldir = np.array(list(scene.lights[k].direction), dtype=np.float64)
+        lcol = np.array(list(scene.lights[k].color), dtype=np.float64)
+        r = _normalize(np.broadcast_to(-ldir, p.shape))
+        occ_i, _ = _nearest(p, r, spheres, 0.001, 1000.0)
+        w = np.maximum(0.0, (r * n).sum(axis=1))[:, None]
+        tint = (albedo * 0.25 + lcol * 0.75) * (refr * 0.75)[:, None]
+        diffuse += np.where((occ_i >= 0)[:, None], tint, lcol) * w
+        v = -d
+        vdn = np.clip((v * n).sum(axis=1), 0.0, 1.0)
+        ndl = np.clip((n * -ldir).sum(axis=1), 0.0, 1.0)
+        h = -_normalize(ldir + d)
+        ndh = np.clip((n * h).sum(axis=1), EPS, 1.0)
+        vdh = np.clip((v * h).sum(axis=1), 0.0, 1.0)
+        g = np.where(np.abs(vdh) >= EPS, np.minimum(1.0, 2.0 * ndh * np.minimum(vdn, ndl) / np.maximum(vdh, 1e-300)), 1.0)
+        r2 = np.maximum(rough, 0.03) ** 2
+        with np.errstate(under="ignore", over="ignore"):
+            dm = np.exp((ndh ** 2 - 1.0) / (r2 * ndh ** 2)) / (4.0 * r2 * ndh ** 4)
+        f0 = (1.0 - refr) / (1.0 + refr)
+        f = f0 ** 2 + (1.0 - f0 ** 2) * (1.0 - vdn) ** 5
+        spec += (lcol * 0.5 + albedo * 0.5) * np.clip(g * dm * f, 0.0, 1.0)[:, None]
+    return diffuse, spec
+
+
+def render_full_depth(scene, width, height, s_row, max_depth=10):
+    """The whole deterministic path (ballRand == 0, glass draw == 0.5): up to max_depth bounces, reverse
+    accumulation with the energy early-out (demos/demo_frame_cpu.cpp:22-76).  float64 rgb[h, w, 3]."""
+    cam = scene.camera
+    pos = np.array(list(cam.position), dtype=np.float64)
+    direction = np.array(list(cam.direction), dtype=np.float64)
+    background = np.array(list(cam.background), dtype=np.float64)
+    spheres = [tuple(float(x) for x in row) for row in scene.centers_radii]
+    centres_all = np.array([s[:3] for s in spheres]).reshape(-1, 3)
+    right = np.cross(np.array([0.0, 1.0, 0.0]), direction)
+    up = np.cross(direction, right)
+    dw = cam.znear / np.tan(0.5 * cam.fov)
+    dh = dw * height / width
+    cell_x, cell_y = 2.0 * dw / width, 2.0 * dh / height
+    ys, xs, sxs, sys_ = np.meshgrid(np.arange(height), np.arange(width), np.arange(s_row), np.arange(s_row), indexing="ij")
+    dx = (2.0 * xs / width - 1.0) * dw + cell_x * sxs / s_row
+    dy = (-2.0 * ys / height + 1.0) * dh - cell_y * sys_ / s_row
+    dirs = _normalize(direction * cam.znear + up * dy[..., None] + right * dx[..., None]).reshape(-1, 3)
+    count_rays = dirs.shape[0]
+    origins = np.broadcast_to(pos, dirs.shape).copy()
+
+    mat_type = np.array([scene.materials[i].type for i in range(scene.material_count)])
+    mat_albedo = np.array([list(scene.materials[i].albedo) for i in range(scene.material_count)], dtype=np.float64).reshape(-1, 3)
+    mat_rough = np.array([scene.materials[i].roughness for i in range(scene.material_count)], dtype=np.float64)
+    mat_refr = np.array([scene.materials[i].refraction for i in range(scene.material_count)], dtype=np.float64)
+
+    l_stack = np.zeros((max_depth, count_rays, 3))
+    e_stack = np.ones((max_depth, count_rays))
+    n_entries = np.zeros(count_rays, dtype=np.int64)
+    active = np.ones(count_rays, dtype=bool)
+    znear = np.full(count_rays, float(cam.znear))
+    for depth in range(max_depth):
+        idx = np.nonzero(active)[0]
+        if idx.size == 0:
+            break
+        hit_i, hit_t = _nearest(origins[idx], dirs[idx], spheres, znear[idx], cam.zfar)
+        miss = hit_i < 0
+        active[idx[miss]] = False
+        idx, hit_i, hit_t = idx[~miss], hit_i[~miss], hit_t[~miss]
+        if idx.size == 0:
+            break
+        d = dirs[idx]
+        p = origins[idx] + d * hit_t[:, None]
+        n = _normalize(p - centres_all[hit_i])
+        mi = scene.material_index[hit_i].astype(np.int64)
+        mtype, albedo, rough, refr = mat_type[mi], mat_albedo[mi], mat_rough[mi], mat_refr[mi]
+
+        dn = (n * d).sum(axis=1, keepdims=True)
+        refl = d - n * dn * 2.0
+        # Matte: n + 0; Metal: reflect + 0 * roughness; both normalised
+        out_matte = _normalize(n)
+        out_metal = _normalize(refl)
+        e_metal = np.where((n * out_metal).sum(axis=1) <= 0.0, 0.0, 0.9 * (1.0 - rough))
+        # Glass (default_materials.cpp:35-67)
+        vdn = (d * n).sum(axis=1)
+        inside = vdn > 0.0
+        outward = np.where(inside[:, None], -n, n)
+        eta = np.where(inside, refr, 1.0 / np.where(refr == 0.0, 1.0, refr))
+        vdn_g = np.where(inside, vdn * eta, -vdn)
+        dd = (outward * d).sum(axis=1)
+        k = 1.0 - eta * eta * (1.0 - dd * dd)
+        refr_dir = np.where((k >= 0.0)[:, None], d * eta[:, None] - outward * (eta * dd + np.sqrt(np.maximum(k, 0.0)))[:, None], 0.0)
+        f0 = (1.0 - refr) / (1.0 + refr)
+        ref = np.where((refr_dir * refr_dir).sum(axis=1) > EPS, f0 ** 2 + (1.0 - f0 ** 2) * (1.0 - vdn_g) ** 5, 1.0)
+        out_glass = np.where((0.5 < ref)[:, None], refl, refr_dir)
+
+        out_dir = np.where((mtype == 0)[:, None], out_matte, np.where((mtype == 1)[:, None], out_metal, out_glass))
+        e = np.where(mtype == 0, 0.7, np.where(mtype == 1, e_metal, 1.0))
+
+        absorbed = np.abs(e) < EPS
+        diffuse, spec = _light_terms(scene, spheres, p, d, n, albedo, rough, refr)
+        l = np.where(absorbed[:, None], background, albedo + diffuse + spec)
+        l_stack[depth, idx] = l
+        e_stack[depth, idx] = np.where(absorbed, 1.0, e)
+        n_entries[idx] = depth + 1
+        active[idx[absorbed]] = False
+        origins[idx] = p
+        dirs[idx] = out_dir
+        znear[idx] = 0.001
+
+    # reverse accumulation with the early-out
+    att = np.ones((count_rays, 3))
+    rest = np.ones(count_rays)
+    running = n_entries > 0
+    going = running.copy()
+    for i in range(max_depth - 1, -1, -1):
+        use = going & (n_entries > i)
+        att = np.where(use[:, None], att * (l_stack[i] * rest[:, None]), att)
+        rest = np.where(use, rest * e_stack[i], rest)
+        going &= ~(use & (np.abs(rest) < EPS))
+    colour = np.where(running[:, None], 0.5 * att, background)
+    return colour.reshape(height, width, s_row * s_row, 3).mean(axis=2)

@@ -187,3 +187,23 @@ def test_depth_one_frames_against_an_independent_numpy_statement(oracle, ffi, sc
     assert (err > 1e-4).mean() < 0.01, "pixels off: %d" % int((err > 1e-4).sum())
     assert np.median(err) < 1e-5
     assert abs(float(out.mean()) - float(ref.mean())) < 1e-3
+
+
+@pytest.mark.parametrize("demo,spheres", [(1, 0), (2, 0), (3, 120)])
+def test_full_depth_deterministic_frames_against_numpy(oracle, ffi, scenes, demo, spheres):
+    """The bounce loop, the three materials' deterministic scattering (glass refraction included) and the reverse
+    accumulation, against the separate numpy statement.  Deep glass paths amplify float32 rounding, so the bar is
+    on the bulk of the pixels and on the mean."""
+    import numpy_d1
+
+    scene = scenes(demo, 1, spheres or 10000)
+    w, h, s = 40, 30, 2
+    ref = numpy_d1.render_full_depth(scene, w, h, s)
+    out, _ = oracle.render(scene, ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC), 4)
+    err = np.abs(out - ref).max(axis=2) / np.maximum(np.abs(ref).max(axis=2), 1e-3)
+    assert (err > 1e-3).mean() < 0.03, "pixels off: %d of %d" % (int((err > 1e-3).sum()), err.size)
+    assert np.median(err) < 1e-5
+    assert abs(float(out.mean()) - float(ref.mean())) < 2e-3
+    # and depth 1 of the same function is the depth-1 statement
+    np.testing.assert_allclose(numpy_d1.render_full_depth(scene, 16, 12, 2, max_depth=1),
+                               numpy_d1.render_d1(scene, 16, 12, 2), rtol=1e-9, atol=1e-12)
