@@ -228,6 +228,8 @@ def main():
             "mean_radiance": round(mean_radiance, 5),
             "roofline": {
                 "bound": "valu_fp32",
+                "bound_note": "FP32 vector-ALU issue; this kernel is neither HBM- nor MFMA-bound "
+                              "(0.43 GB of HBM traffic per 3.2 TFLOP launch, no matrix work)",
                 "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
