@@ -251,10 +251,22 @@ struct TraceArgs
   float * partial;            // this slice's column sums, RGB interleaved, in slice order: item slice_index +
                               // slice_count * k is entry k (partial[3 * k + c])
   uint32_t n_items;           // width * height * s_row
-  uint32_t * queue_counter;   // next work item of this slice to hand out
+  uint32_t n_positions;       // columns this slice owns = length of its work queue; position k is column k of the
+                              // slice, item slice_index + slice_count * k of the frame
+  uint32_t * queue_counter;   // next queue position of this slice to hand out
   uint32_t batch_items;       // queue positions a wave reserves at a time
   const uint32_t * cancel;    // non-zero: stop handing out work (host-visible memory, read on refills only)
   unsigned long long * stats; // counters, see rt_hip.hip
+  // Sample sharing at the end of the queue (optional, share_depth = 0: off).  Once a wave finds the queue used
+  // up, its idle lanes take not-yet-started samples off the columns its busy lanes still work on.  A shared
+  // sample's colour goes to shared[3 * (region * share_depth + (s_row - 1 - sy))], where `region` names the lane
+  // that owns the column; the owner stores the sum of the samples it kept, appends (slot, first shared sy,
+  // region * share_depth, 0) to `splits`, and fold_split adds the shared colours in sample order afterwards, so
+  // the column sum is the same floating-point sum whoever traced the samples.
+  float * shared;
+  u4 * splits;
+  uint32_t * split_count;
+  uint32_t share_depth;       // samples at the end of a column that may be shared (<= s_row)
 };
 
 #define RT_REGION_COUNT 12
@@ -332,15 +344,18 @@ RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, f
   return !(disc < 0.0f) && !(t < tmin || t > tmax);  // the reference's two rejections, NaNs included
 }
 
+constexpr uint32_t RT_SHARED_SLOT = 0x80000000u;
+
 // Per-lane state.
 struct Lane
 {
   // work item being accumulated: sub-sample column sx of one pixel (its s_row samples sy = 0..s_row-1)
-  uint32_t item;    // pixel * s_row + sx
-  uint32_t slot;    // position of the item in this slice (where its column sum goes)
+  uint32_t slot;    // position of the item in this slice (where its column sum goes); with RT_SHARED_SLOT set,
+                    // the lane traces a shared sample and the rest is its index in TraceArgs::shared
   uint32_t pixel;
   uint32_t sx;
-  uint32_t sy;      // next sample of the column (>= s_row: none left)
+  uint32_t sy;      // next sample of the column
+  uint32_t sy_end;  // one past the last sample this lane traces itself (s_row unless samples were shared out)
   float sdx, dyp;   // sdx of the column, dy of the pixel (ray_tracing/frame.cpp:49,52,58)
   f3 sum;
   bool alive, need_item;
@@ -376,22 +391,70 @@ RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
   uint32_t const sx = item - pixel * A.s_row;
   uint32_t const y = pixel / A.width;
   uint32_t const x = pixel - y * A.width;
-  L.item = item;
   L.pixel = pixel;
   L.sx = sx;
   L.sy = 0;
+  L.sy_end = A.s_row;
   L.dyp = (-2.0f * (float)y / (float)A.height + 1.0f) * A.dh;        // frame.cpp:49
   float const dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;  // frame.cpp:52
   L.sdx = dxp + A.cell_x * (float)sx / (float)A.s_row;                 // frame.cpp:58
   L.sum = mk3(0.0f, 0.0f, 0.0f);
 }
 
+// Column `slot` of the slice as an item (pixel * s_row + sx) of the frame.
+RT_FN uint32_t slice_item(const TraceArgs & A, uint32_t slot) { return A.slice_index + A.slice_count * slot; }
+
+// Samples a lane can share out right now (see TraceArgs::shared): those of its own column it has not started,
+// less the one it is about to start, and only the last share_depth of the column.
+RT_FN uint32_t spare_samples(const TraceArgs & A, const Lane & L)
+{
+  if (!L.alive || L.need_item || (L.slot & RT_SHARED_SLOT) != 0u)
+    return 0u;
+  uint32_t const keep = (!L.has_hit && !L.shading) ? 1u : 0u;
+  uint32_t const first_shareable = (A.s_row > A.share_depth) ? A.s_row - A.share_depth : 0u;
+  uint32_t const from = (L.sy + keep > first_shareable) ? L.sy + keep : first_shareable;
+  return (L.sy_end > from) ? L.sy_end - from : 0u;
+}
+
+// Makes an idle lane trace sample sy of the column another lane owns (the owner's ray set-up is passed in).
+RT_FN void take_shared_sample(const TraceArgs & A, Lane & L, uint32_t region_base, uint32_t pixel,
+                              uint32_t sx, float sdx, float dyp, uint32_t cm0, uint32_t cm1, uint32_t sy)
+{
+  L.pixel = pixel;
+  L.sx = sx;
+  L.sdx = sdx;
+  L.dyp = dyp;
+  L.cm0 = cm0;
+  L.cm1 = cm1;
+  L.sy = sy;
+  L.sy_end = sy + 1u;
+  L.sum = mk3(0.0f, 0.0f, 0.0f);
+  L.slot = RT_SHARED_SLOT | (region_base + (A.s_row - 1u - sy));
+  L.alive = true;
+  L.need_item = false;
+  L.has_hit = false;
+  L.shading = false;
+}
+
+// Completes the sum of a column whose last samples were traced by other lanes: the owner's partial sum, then
+// the shared colours in increasing sy, the additions the owner would have made itself.
+RT_FN void fold_split(float * partial, const float * shared, u4 rec, uint32_t s_row)
+{
+  float * const c = partial + 3u * (size_t)rec.x;
+  f3 sum = mk3(c[0], c[1], c[2]);
+  for (uint32_t sy = rec.y; sy < s_row; ++sy)
+  {
+    const float * const v = shared + 3u * (size_t)(rec.z + (s_row - 1u - sy));
+    sum = sum + mk3(v[0], v[1], v[2]);
+  }
+  store3(c, sum);
+}
+
 // What an environment hands out with a work item.  When `prepared`, the column's ray set-up and candidate
 // masks were computed ahead (prepare_column); otherwise the lane runs begin_item itself.
 struct ItemInfo
 {
-  uint32_t item;          // RT_INVALID: the slice is used up
-  uint32_t slot;          // position of the item in its slice: item = slice_index + slice_count * slot
+  uint32_t pos;           // queue position; RT_INVALID: the slice is used up
   bool prepared;
   float sdx, dyp;
   uint32_t cm0, cm1, pixel, sx;
@@ -655,7 +718,7 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //                     sphere tiles are re-staged inside the loop)
 //   count(p)          number of such lanes for which p holds
 //   any_wave(p)       true if p holds for any lane of the wave
-//   fetch_item(need, info)  hands a fresh work item to each lane that asks (info.item == RT_INVALID when the
+//   fetch_item(need, info)  hands a fresh work item to each lane that asks (info.pos == RT_INVALID when the
 //                     slice is used up), prepared or not (see ItemInfo)
 //   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i);  material(m, k) and
 //                     light(l, k): record k of material m / light l;  jitter_table()
@@ -961,11 +1024,11 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
   L.need_item = true;
   L.has_hit = false;
   L.shading = false;
-  L.item = 0;
   L.slot = 0;
   L.pixel = 0;
   L.sx = 0;
   L.sy = 0;
+  L.sy_end = 0;
   L.depth = 0;
   L.sample = 0;
   L.li = 0;
@@ -987,10 +1050,14 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     {
       cnt.rounds += 1;
       bool need = L.alive && !L.has_hit && !L.shading;
-      // Column complete: one 12-byte store; every item is written by exactly one lane.
-      if (need && !L.need_item && L.sy >= A.s_row)
+      // Column (or shared sample) complete: one 12-byte store; every entry is written by exactly one lane.
+      if (need && !L.need_item && L.sy >= L.sy_end)
       {
-        store3(A.partial + 3u * (size_t)L.slot, L.sum);
+        bool const shared_sample = (L.slot & RT_SHARED_SLOT) != 0u;
+        float * const dst = shared_sample ? A.shared : A.partial;
+        store3(dst + 3u * (size_t)(L.slot & ~RT_SHARED_SLOT), L.sum);
+        if (!shared_sample && L.sy_end < A.s_row)
+          env.record_split(L.slot, L.sy_end);
         L.need_item = true;
       }
       bool const ask = need && L.need_item;
@@ -1001,17 +1068,17 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         cnt.filter_tests += info.filter_tests;
         if (ask)
         {
-          if (info.item == RT_INVALID)
+          if (info.pos == RT_INVALID)
             L.alive = false;
           else
           {
-            L.slot = info.slot;
+            L.slot = info.pos;
             if (info.prepared)
             {
-              L.item = info.item;
               L.pixel = info.pixel;
               L.sx = info.sx;
               L.sy = 0;
+              L.sy_end = A.s_row;
               L.sdx = info.sdx;
               L.dyp = info.dyp;
               L.cm0 = info.cm0;
@@ -1019,12 +1086,15 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
               L.sum = mk3(0.0f, 0.0f, 0.0f);
             }
             else
-              begin_item(A, L, info.item);
+              begin_item(A, L, slice_item(A, L.slot));
             L.need_item = false;
           }
         }
       }
-      bool const active = need && L.alive;
+      // The queue is used up for this wave: idle lanes take samples off the busy lanes' columns.
+      if (env.endgame())
+        env.share(L);
+      bool const active = L.alive && !L.has_hit && !L.shading;  // a lane that asked has its item, or is idle now
       RT_REGION(cnt, 0);
       if (env.any(active))
       {

@@ -58,7 +58,19 @@ constexpr uint32_t kStatsWords = 8;
 // multiple of kItemBatch chosen by the host: a single counter word sustains well under a hundred reservations
 // per microsecond, far fewer than the waves would ask for item by item, or even batch by batch when columns
 // are short).  The wave works through its reservation in windows of kItemBatch, serving its lanes from the
-// window with a ballot and a prefix count.  The k-th item of slice r out of g is r + g * k.
+// window with a ballot and a prefix count.  Position k of the queue is column k of the slice.
+#if defined(RT_PROFILE_REGIONS)
+// Per wave of the resident kernel: constant-rate clock (100 MHz) at entry, after staging, after the loop, and when the
+// wave found the queue used up.
+constexpr uint32_t kTimelineWaves = 8192;
+__device__ unsigned long long g_wave_times[4 * kTimelineWaves];
+__device__ __forceinline__ void timeline_mark(uint32_t k)
+{
+  uint32_t const wave = blockIdx.x * (kBlock / 64u) + threadIdx.x / 64u;
+  if (__lane_id() == 0 && wave < kTimelineWaves)
+    g_wave_times[4u * wave + k] = wall_clock64();
+}
+#endif
 constexpr uint32_t kItemBatch = 64;
 constexpr uint32_t kCancelPoll = 8;
 
@@ -67,6 +79,7 @@ struct ItemPool
   uint32_t next = 0, end = 0;  // the current window, wave-uniform
   uint32_t reserved_end = 0;   // end of the wave's reservation
   uint32_t refills = 0;
+  bool exhausted = false;      // the last reservation lay past the end of the queue: nothing more will come
 
   // Opens the next window: the rest of the reservation, or a new reservation.
   __device__ __forceinline__ void refill(const TraceArgs & A)
@@ -86,15 +99,20 @@ struct ItemPool
       refills += 1u;
       end = __builtin_amdgcn_readfirstlane(base);
       reserved_end = end + A.batch_items;
+      exhausted = end >= A.n_positions;
+#if defined(RT_PROFILE_REGIONS)
+      if (exhausted)
+        timeline_mark(3);
+#endif
     }
     next = end;
     end = next + kItemBatch;
   }
 
-  __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need, uint32_t & slot)
+  // The queue position handed to this lane, or RT_INVALID.
+  __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need)
   {
     uint32_t result = RT_INVALID;
-    slot = 0u;
     uint32_t const lane = __lane_id();
     for (;;)
     {
@@ -102,16 +120,17 @@ struct ItemPool
       if (mask == 0ull)
         break;
       if (next == end)
+      {
+        if (exhausted)
+          break;
         refill(A);
+      }
       uint32_t const avail = end - next;
       uint32_t const wanted = (uint32_t)__popcll(mask);
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (need && rank < avail)
       {
-        unsigned long long const q = (unsigned long long)A.slice_index +
-                                     (unsigned long long)A.slice_count * (unsigned long long)(next + rank);
-        result = q < (unsigned long long)A.n_items ? (uint32_t)q : RT_INVALID;
-        slot = next + rank;
+        result = (next + rank < A.n_positions) ? next + rank : RT_INVALID;
         need = false;
       }
       next += wanted < avail ? wanted : avail;
@@ -119,6 +138,67 @@ struct ItemPool
     return result;
   }
 };
+
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, uint32_t lane)
+{
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+__device__ __forceinline__ float lane_value(float v, uint32_t lane)
+{
+  return __uint_as_float(lane_value(__float_as_uint(v), lane));
+}
+
+// Sample sharing inside a wave, once the queue is used up (TraceArgs::shared): the idle lanes are dealt out
+// to the lanes that still have samples to start, an even share each, taking samples from the end of the
+// owner's column.  Everything here is wave-wide and needs no memory traffic: the owner's ray set-up travels
+// through lane reads.  The region of a lane is its index in the launch, so no two owners share one.
+__device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L)
+{
+  if (A.share_depth == 0u)
+    return;
+  unsigned long long const idle = __ballot(!L.alive);
+  if (idle == 0ull)
+    return;
+  uint32_t const spare = spare_samples(A, L);
+  unsigned long long donors = __ballot(spare != 0u);
+  if (donors == 0ull)
+    return;
+  uint32_t const lane = __lane_id();
+  uint32_t const n_idle = (uint32_t)__popcll(idle);
+  uint32_t const per = max(1u, n_idle / (uint32_t)__popcll(donors));
+  uint32_t const my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+  bool const was_idle = !L.alive;
+  uint32_t const wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
+  uint32_t taken = 0u;
+  while (donors != 0ull && taken < n_idle)
+  {
+    uint32_t const d = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(donors));
+    donors &= donors - 1ull;
+    uint32_t const give = min(min(lane_value(spare, d), per), n_idle - taken);
+    uint32_t const d_end = lane_value(L.sy_end, d);
+    uint32_t const d_pixel = lane_value(L.pixel, d), d_sx = lane_value(L.sx, d);
+    uint32_t const d_cm0 = lane_value(L.cm0, d), d_cm1 = lane_value(L.cm1, d);
+    float const d_sdx = lane_value(L.sdx, d), d_dyp = lane_value(L.dyp, d);
+    if (lane == d)
+      L.sy_end = d_end - give;
+    if (was_idle && my_rank >= taken && my_rank < taken + give)
+      take_shared_sample(A, L, (wave_first + d) * A.share_depth, d_pixel, d_sx, d_sdx, d_dyp, d_cm0, d_cm1,
+                         d_end - 1u - (my_rank - taken));
+    taken += give;
+  }
+}
+
+// The owner of a column some of whose samples were shared out leaves a record for the fold pass.
+__device__ __forceinline__ void append_split(const TraceArgs & A, uint32_t slot, uint32_t first_shared_sy)
+{
+  uint32_t const at = atomicAdd(A.split_count, 1u);
+  u4 rec;
+  rec.x = slot;
+  rec.y = first_shared_sy;
+  rec.z = (blockIdx.x * blockDim.x + threadIdx.x) * A.share_depth;
+  rec.w = 0u;
+  A.splits[at] = rec;
+}
 
 // The whole scene is resident in LDS; waves never wait for each other.
 struct WaveEnv
@@ -137,6 +217,9 @@ struct WaveEnv
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
+  __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
+  __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[RT_MAT_RECORDS * m + k]; }
@@ -147,18 +230,17 @@ struct WaveEnv
   __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return A.n_padded; }
   __device__ __forceinline__ const f4 * tile_data(bool primary) const { return primary ? cam : filt; }
 
-  // With column masks the wave prepares a whole batch when it reserves one: lane l sets up the column at
-  // queue position base + l (ray set-up and candidate masks, one filter pass per column instead of one per
-  // sample) and parks it in the wave's LDS table, from where the lanes pick their items up.
+  // With column masks the wave prepares a whole window when it opens one: lane l sets up the column at queue
+  // position base + l (ray set-up and candidate masks, one filter pass per column instead of one per sample)
+  // and parks it in the wave's LDS table, from where the lanes pick their columns up.
   __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
   {
-    info.item = RT_INVALID;
+    info.pos = RT_INVALID;
     info.prepared = false;
     info.filter_tests = 0u;
-    info.slot = 0u;
     if (A.column_masks == 0u)
     {
-      info.item = pool.fetch(A, need, info.slot);
+      info.pos = pool.fetch(A, need);
       return;
     }
     uint32_t const lane = __lane_id();
@@ -169,14 +251,14 @@ struct WaveEnv
         break;
       if (pool.next == pool.end)
       {
+        if (pool.exhausted)
+          break;
         pool.refill(A);
-        unsigned long long const q = (unsigned long long)A.slice_index +
-                                     (unsigned long long)A.slice_count * (unsigned long long)(pool.next + lane);
         ColumnEntry e;
         e.pixel = RT_INVALID;
-        if (q < (unsigned long long)A.n_items)
+        if (pool.next + lane < A.n_positions)
         {
-          e = prepare_column(A, cam, (uint32_t)q);
+          e = prepare_column(A, cam, slice_item(A, pool.next + lane));
           info.filter_tests += 1u;
         }
         batch[lane] = e;
@@ -190,8 +272,7 @@ struct WaveEnv
         ColumnEntry const e = batch[pool.next + rank - (pool.end - kItemBatch)];
         if (e.pixel != RT_INVALID)
         {
-          info.item = e.pixel * A.s_row + e.sx;
-          info.slot = pool.next + rank;
+          info.pos = pool.next + rank;
           info.prepared = true;
           info.sdx = e.sdx;
           info.dyp = e.dyp;
@@ -220,11 +301,14 @@ struct BlockEnv
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
+  __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
+  __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
   __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
   {
     info.prepared = false;
     info.filter_tests = 0u;
-    info.item = pool.fetch(A, need, info.slot);
+    info.pos = pool.fetch(A, need);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -259,11 +343,14 @@ struct GridEnv
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
+  __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
+  __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
   __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
   {
     info.prepared = false;
     info.filter_tests = 0u;
-    info.item = pool.fetch(A, need, info.slot);
+    info.pos = pool.fetch(A, need);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -330,6 +417,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   LaneCounters cnt = {};
 #if defined(RT_PROFILE_REGIONS)
   cnt.last_tick = __builtin_amdgcn_s_memtime();
+  timeline_mark(0);
 #endif
   // both layouts start with the jitter table
   float * jitter = reinterpret_cast<float *>(sph);
@@ -360,8 +448,14 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     for (uint32_t i = threadIdx.x; i < 2u * A.n_lights; i += kBlock)
       lights[i] = A.lights[i];
     __syncthreads();
+#if defined(RT_PROFILE_REGIONS)
+    timeline_mark(1);
+#endif
     WaveEnv env{A, sph, cam, exact, mats, lights, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
     trace_loop<kForward, false>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+#if defined(RT_PROFILE_REGIONS)
+    timeline_mark(2);
+#endif
   }
 
   flush_counters(A, cnt);
@@ -404,6 +498,17 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
   float const len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f;
   e.w = filter_bound(dx, dy, dz, s.w) - len * col_delta;
   camtab[i] = e;
+}
+
+// After a trace with sample sharing: completes the column sums whose last samples other lanes traced.  One
+// lane per record; the records of a launch are at most one per lane of its grid.
+__global__ __launch_bounds__(256) void fold_kernel(float * __restrict__ partial, const float * __restrict__ shared,
+                                                   const u4 * __restrict__ splits,
+                                                   const uint32_t * __restrict__ split_count, uint32_t s_row)
+{
+  uint32_t const n = *split_count;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    fold_split(partial, shared, splits[i], s_row);
 }
 
 // The accumulate pass: per pixel, the column sums this slice owns are added in increasing sx (the order
@@ -550,7 +655,7 @@ struct rt_hip_job
   rt_hip_trace_params params;
   size_t partial_size = 0;  // bytes behind d_partial
   size_t pixels = 0;        // pixels behind d_planes / d_rgb
-  float * d_partial = nullptr;  // the slice's column sums, RGB interleaved (partial_bytes)
+  float * d_partial = nullptr;  // the slice's column sums, RGB interleaved, then sample-sharing room (trace_buffer_bytes)
   float * d_planes = nullptr;
   float * d_rgb = nullptr;
   unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
@@ -572,6 +677,9 @@ uint32_t forced_tile()
   uint32_t const n = (uint32_t)std::strtoul(v, nullptr, 10);
   return std::min(std::max(n, 1u), kTileSpheres);
 }
+
+// RT_HIP_NO_SHARING (any value) switches sample sharing at the end of the queue off, for comparisons.
+bool share_disabled() { return std::getenv("RT_HIP_NO_SHARING") != nullptr; }
 
 bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }
 
@@ -645,6 +753,43 @@ uint32_t batch_items(const rt_hip_trace_params * p, int compute_units)
   return (uint32_t)(k * kItemBatch);
 }
 
+// The end of a launch: a wave that finds the queue used up spreads the samples its busy lanes have not started
+// over its idle lanes (up to kShareDepth samples at the end of a column), so it finishes when its work does,
+// not when its slowest column does.  That needs room behind the column sums: a 16-byte header with the record
+// count, then one record and share_depth colours per lane of the grid.
+constexpr uint32_t kShareDepth = 64;
+uint32_t share_depth(const rt_hip_trace_params * p) { return std::min(p->samples_in_row, kShareDepth); }
+size_t share_bytes_for(size_t lanes, uint32_t depth) { return 16u + lanes * (sizeof(u4) + 3u * sizeof(float) * depth); }
+unsigned long long slice_columns(const rt_hip_trace_params * p)
+{
+  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
+  unsigned long long const r = p->slice_count ? p->slice_index : 0u;
+  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
+  return (items > r) ? (items - r + g - 1u) / g : 0u;
+}
+// Enough for any grid this frame can be traced with.
+size_t share_bytes(const rt_hip_trace_params * p)
+{
+  unsigned long long const columns = slice_columns(p);
+  unsigned long long const chip = (unsigned long long)std::max(g_lib.compute_units, 1) * 4u * kWavesPerSimdForward * 64u;
+  size_t const lanes = (size_t)std::min(chip, (columns + kBlock - 1u) / kBlock * kBlock);
+  return share_bytes_for(lanes, share_depth(p));
+}
+
+// Column sums of one slice: 12 bytes per owned column.
+size_t partial_bytes(const rt_hip_trace_params * p)
+{
+  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
+  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
+  return 3 * sizeof(float) * (size_t)((items + g - 1u) / g);
+}
+
+// A trace's output buffer: the column sums, then (256-byte aligned) the room sample sharing needs.
+size_t trace_buffer_bytes(const rt_hip_trace_params * p)
+{
+  return ((partial_bytes(p) + 255u) & ~(size_t)255u) + share_bytes(p);
+}
+
 int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p)
 {
   if (!g_lib.ready)
@@ -664,13 +809,15 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
   return RT_HIP_OK;
 }
 
-// Enqueues, on `stream`: counter reset, the camera table for this frame's camera, the trace kernel.
-// d_partial receives the column sums of this slice; d_stats points at kStatsWords counters followed by the
+// Enqueues, on `stream`: counter reset, the camera table for this frame's camera, the trace kernel and, with
+// sample sharing, the fold pass.  d_partial receives the column sums of this slice; `capacity` is the size of
+// the buffer behind it: sample sharing is on when it has room for the records and colours behind the column
+// sums (trace_buffer_bytes). d_stats points at kStatsWords counters followed by the
 // queue counter (one 8-byte slot).  When events are given they are recorded directly around the trace
 // kernel.  The camera table lives in the scene, so one scene carries one trace at a time.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
                  float * d_partial, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, const uint32_t * d_cancel = nullptr)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, size_t capacity, const uint32_t * d_cancel = nullptr)
 {
   TraceArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -716,9 +863,22 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
                        scene->n_padded, a.cam_pos, a.col_delta);
     RT_CHECK(hipGetLastError());
   }
-  unsigned long long const my_items = ((unsigned long long)a.n_items + a.slice_count - 1u) / a.slice_count;
+  unsigned long long const my_items = slice_columns(p);
   int const blocks = persistent_blocks(scene, p->flags, my_items, d_cancel != nullptr);
   size_t const lds = lds_bytes(scene, p->flags);
+  a.n_positions = (uint32_t)my_items;
+  // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
+  size_t const lanes = (size_t)blocks * kBlock;
+  size_t const share_at = (partial_bytes(p) + 255u) & ~(size_t)255u;
+  if (capacity >= share_at + share_bytes_for(lanes, share_depth(p)) && !share_disabled())
+  {
+    unsigned char * const base = reinterpret_cast<unsigned char *>(d_partial) + share_at;
+    a.split_count = reinterpret_cast<uint32_t *>(base);
+    a.splits = reinterpret_cast<u4 *>(base + 16);
+    a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
+    a.share_depth = share_depth(p);
+    RT_CHECK(hipMemsetAsync(a.split_count, 0, 16, stream));
+  }
   if (ev_start)
     RT_CHECK(hipEventRecord(ev_start, stream));
   (void)with_trace_kernel(scene, p->flags, [&](auto kernel) {
@@ -726,6 +886,12 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     return hipSuccess;
   });
   RT_CHECK(hipGetLastError());
+  if (a.share_depth != 0u)
+  {
+    hipLaunchKernelGGL(fold_kernel, dim3(std::min(blocks, 256)), dim3(256), 0, stream, d_partial, a.shared, a.splits,
+                       a.split_count, a.s_row);
+    RT_CHECK(hipGetLastError());
+  }
   if (ev_stop)
     RT_CHECK(hipEventRecord(ev_stop, stream));
   return RT_HIP_OK;
@@ -740,14 +906,6 @@ int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_
                      p->slice_index % g, g);
   RT_CHECK(hipGetLastError());
   return RT_HIP_OK;
-}
-
-// Column sums of one slice: 12 bytes per owned column.
-size_t partial_bytes(const rt_hip_trace_params * p)
-{
-  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
-  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
-  return 3 * sizeof(float) * (size_t)((items + g - 1u) / g);
 }
 
 int launch_resolve(const float * d_planes, float * d_rgb, uint32_t width, uint32_t height, uint32_t s_row,
@@ -810,7 +968,7 @@ void free_job(rt_hip_job * job)
 // A job object with buffers for `params`: the spare one if it fits, else a fresh one.
 rt_hip_job * acquire_job(const rt_hip_trace_params * params, hipError_t & e)
 {
-  size_t const need = partial_bytes(params);
+  size_t const need = trace_buffer_bytes(params);
   size_t const pixels = (size_t)params->width * params->height;
   rt_hip_job * job = nullptr;
   {
@@ -1065,7 +1223,7 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   }
   rc = launch_trace(scene, camera, params, job->d_partial, job->d_stats, true, g_lib.stream, job->start,
-                    job->stop, d_cancel);
+                    job->stop, job->partial_size, d_cancel);
   if (rc != RT_HIP_OK)
   {
     (void)hipStreamSynchronize(g_lib.stream);
@@ -1187,7 +1345,7 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
     st = s_scratch;
   }
   // Column sums go to a library workspace that only ever grows; the planes are accumulated from it.
-  size_t const need = partial_bytes(params);
+  size_t const need = trace_buffer_bytes(params);
   if (g_lib.workspace_bytes < need)
   {
     if (g_lib.workspace != nullptr)
@@ -1201,7 +1359,8 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
     g_lib.workspace_bytes = need;
   }
   hipStream_t const hs = static_cast<hipStream_t>(stream);
-  int rc2 = launch_trace(scene, camera, params, g_lib.workspace, st, d_stats != nullptr, hs, nullptr, nullptr);
+  int rc2 = launch_trace(scene, camera, params, g_lib.workspace, st, d_stats != nullptr, hs, nullptr, nullptr,
+                         g_lib.workspace_bytes);
   if (rc2 == RT_HIP_OK)
     rc2 = launch_colsum(g_lib.workspace, d_sum_planes, params, hs);
   return rc2;
@@ -1229,14 +1388,15 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
   float * d_planes = nullptr;  // column sums
   unsigned long long * d_stats = nullptr;
   hipEvent_t start = nullptr, stop = nullptr;
-  hipError_t e = hipMalloc((void **)&d_planes, partial_bytes(params));
+  hipError_t e = hipMalloc((void **)&d_planes, trace_buffer_bytes(params));
   if (e == hipSuccess) e = hipMalloc((void **)&d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
   if (e == hipSuccess) e = hipEventCreate(&start);
   if (e == hipSuccess) e = hipEventCreate(&stop);
   double total_ms = 0.0;
   for (uint32_t i = 0; e == hipSuccess && rc == RT_HIP_OK && i < launches; ++i)
   {
-    rc = launch_trace(scene, camera, params, d_planes, d_stats, true, g_lib.stream, start, stop);
+    rc = launch_trace(scene, camera, params, d_planes, d_stats, true, g_lib.stream, start, stop,
+                      trace_buffer_bytes(params));
     if (rc != RT_HIP_OK)
       break;
     e = hipEventSynchronize(stop);
@@ -1273,6 +1433,20 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
 }  // extern "C"
 
 #if defined(RT_PROFILE_REGIONS)
+// Profiling builds only: copies out and clears the per-wave timeline of the last resident-kernel launch
+// (four 100 MHz clock readings per wave: entry, staged, done, queue found used up).
+extern "C" int rt_hip_debug_wave_times(unsigned long long * out, int waves)
+{
+  if (waves < 0 || (uint32_t)waves > kTimelineWaves)
+    return RT_HIP_ERR_INVALID;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 4u * (size_t)waves) != hipSuccess)
+    return RT_HIP_ERR_DEVICE;
+  static unsigned long long zero[4 * kTimelineWaves] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_times), zero, sizeof(zero)) != hipSuccess)
+    return RT_HIP_ERR_DEVICE;
+  return RT_HIP_OK;
+}
+
 // Profiling builds only: reads (and clears) the per-region wave clock ticks summed over all waves.
 extern "C" int rt_hip_debug_region_ticks(unsigned long long * out, int count)
 {

@@ -18,25 +18,57 @@ struct HostEnv
   uint32_t cur_count = 0;
   const rtc::f4 * cur = nullptr;
 
+  // Sample-sharing test mode.  The kernel shares samples between the lanes of a wave once its queue is used
+  // up; this one-lane build exercises the same bookkeeping (shortened columns, shared-sample entries, split
+  // records, the fold) by making every column hand its last samples to a list that the lane works off when the
+  // queue is empty.
+  struct SharedSample
+  {
+    uint32_t region_base, pixel, sx, cm0, cm1, sy;
+    float sdx, dyp;
+  };
+  bool share_test = false;
+  std::vector<SharedSample> waiting;
+  std::vector<rtc::u4> splits;
+  bool endgame() const { return share_test; }
+  void share(rtc::Lane & L)
+  {
+    uint32_t const region_base = (uint32_t)splits.size() * A.share_depth;  // one region per split column
+    uint32_t const spare = rtc::spare_samples(A, L);
+    if (spare != 0u)
+    {
+      // a varying number, so that columns are cut at different places (and some not at all)
+      uint32_t const give = (L.pixel + L.sx) % (spare + 1u);
+      for (uint32_t j = 0; j < give; ++j)
+        waiting.push_back({region_base, L.pixel, L.sx, L.cm0, L.cm1, L.sy_end - 1u - j, L.sdx, L.dyp});
+      L.sy_end -= give;
+    }
+    else if (!L.alive && !waiting.empty())
+    {
+      SharedSample const w = waiting.back();
+      waiting.pop_back();
+      rtc::take_shared_sample(A, L, w.region_base, w.pixel, w.sx, w.sdx, w.dyp, w.cm0, w.cm1, w.sy);
+    }
+  }
+  void record_split(uint32_t slot, uint32_t first_shared_sy)
+  {
+    splits.push_back({slot, first_shared_sy, (uint32_t)splits.size() * A.share_depth, 0u});
+  }
+
   bool any(bool p) { return p; }
   int count(bool p) { return p ? 1 : 0; }
   bool any_wave(bool p) { return p; }
   void fetch_item(bool need, rtc::ItemInfo & info)
   {
-    info.item = rtc::RT_INVALID;
-    info.slot = 0;
+    info.pos = rtc::RT_INVALID;
     info.prepared = false;
     info.filter_tests = 0;
-    if (!need)
+    if (!need || next >= A.n_positions)
       return;
-    unsigned long long const q = A.slice_index + (unsigned long long)A.slice_count * next++;
-    if (q >= total)
-      return;
-    info.item = (uint32_t)q;
-    info.slot = next - 1;
+    info.pos = next++;
     if (A.column_masks != 0u)
     {
-      rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, info.item);
+      rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, rtc::slice_item(A, info.pos));
       info.prepared = true;
       info.sdx = e.sdx;
       info.dyp = e.dyp;
@@ -67,11 +99,15 @@ struct HostEnv
 
 // tile_size: records per staged tile (exercises the multi-tile path when smaller than the scene).
 // mode: bit 0 = column masks (scenes of at most 64 spheres, one tile), bit 1 = forward accumulation,
-// bit 2 = rays walk the uniform grid.
+// bit 2 = rays walk the uniform grid, bit 3 = sample-sharing test mode (see HostEnv).
 extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                                const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                                const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
                                uint32_t mode, float * rgb, unsigned long long * stats6);
+
+// Columns of the last frame whose sum was completed by the fold (sample-sharing test mode).
+static unsigned long long g_last_split_count = 0;
+extern "C" unsigned long long emu_last_split_count() { return g_last_split_count; }
 
 extern "C" int emu_forward_ok(const rt_hip_material * mats, uint32_t m)
 {
@@ -131,6 +167,17 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   std::vector<rtc::f4> stack(rtc::RT_MAX_DEPTH);
   rtc::LaneCounters cnt{};
   HostEnv env{a, a.n_items, (tile_size && !column_masks) ? tile_size : (padded ? padded : 4u)};
+  uint32_t const slice_columns =
+      (a.n_items > a.slice_index) ? (a.n_items - a.slice_index + a.slice_count - 1u) / a.slice_count : 0u;
+  a.n_positions = slice_columns;
+  std::vector<float> shared;
+  if ((mode & 8u) != 0u)
+  {
+    env.share_test = true;
+    a.share_depth = s_row;
+    shared.assign(3u * (size_t)a.n_items * a.share_depth, 0.0f);
+    a.shared = shared.data();
+  }
   rtc::GridHost grid;
   if ((mode & 4u) != 0u)
   {
@@ -155,6 +202,12 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     rtc::trace_loop<true, false>(a, env, stack.data(), 1u, cnt);
   else
     rtc::trace_loop<false, false>(a, env, stack.data(), 1u, cnt);
+
+  g_last_split_count = (unsigned long long)env.splits.size();
+  for (rtc::u4 const & rec : env.splits)
+    rtc::fold_split(partial.data(), shared.data(), rec, s_row);
+  if (env.share_test && !env.waiting.empty())
+    return 4;
 
   // accumulate (owned columns in increasing sx) + resolve, as colsum_kernel and resolve_kernel do
   float const inv = 1.0f / static_cast<float>(s_row * s_row);

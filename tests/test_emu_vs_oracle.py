@@ -55,6 +55,21 @@ def test_column_masks_match_per_sample_filtering_bit_for_bit(ffi, scenes):
     assert sa["hit_queries"] == sb["hit_queries"] and sa["ray_queries"] == sb["ray_queries"]
 
 
+@pytest.mark.parametrize("column_masks,forward,tile", [(False, False, 0), (True, True, 0), (False, True, 16)])
+def test_shared_samples_leave_every_bit_of_the_frame_alone(ffi, scenes, column_masks, forward, tile):
+    """Samples at the end of a column may be traced by another lane and folded into the column sum afterwards
+    (what the kernel does when its queue runs dry); the sum must be the same floating-point sum."""
+    for demo, s, flags, slices in ((1, 4, 0, 1), (2, 5, 0, 1), (1, 3, ffi.FLAG_DETERMINISTIC, 1), (1, 4, 0, 3)):
+        scene = scenes(demo)
+        p = ffi.params(48, 36, s, flags=flags, seed=11, slice_index=slices - 1, slice_count=slices)
+        a, sa = emu_ffi.render(scene, p, tile, column_masks=column_masks, forward=forward)
+        b, sb = emu_ffi.render(scene, p, tile, column_masks=column_masks, forward=forward, share=True)
+        np.testing.assert_array_equal(a, b)
+        assert sb["split_columns"] > 0.3 * 48 * 36 * s / slices
+        for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces", "exact_tests"):
+            assert sa[key] == sb[key], key
+
+
 def test_forward_accumulation_is_refused_when_the_energy_break_can_trigger(ffi):
     rough = ffi.Scene.build([(0.0, 0.0, 2.0, 1.0, 0)], [(1, (0.9, 0.9, 0.9), 0.95, 0.1)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
     assert not emu_ffi.forward_ok(rough)

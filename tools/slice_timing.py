@@ -1,0 +1,39 @@
+"""What one rank of G does per frame: the time of rt_hip_trace_device (trace + accumulate pass) on slice 0 of G
+of the headline frame, against 1/G of the whole frame.  Leaves out the RCCL reduce, which needs the other GPUs.
+
+python tools/slice_timing.py [width height samples_in_row [slice counts]]       (RT_LIB_DIR=dir picks another build of the libraries)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from rt_amd import ffi, sharding  # noqa: E402
+
+if os.environ.get("RT_LIB_DIR"):
+    ffi._LIB_DIR = os.path.abspath(os.environ["RT_LIB_DIR"])
+
+r = ffi.HipRenderer(0)
+scene = ffi.Scene.demo(1, 1)
+w, h, s = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1920, 1080, 16)
+planes = torch.empty(3 * w * h, dtype=torch.float32, device="cuda")
+stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+base = None
+for g in ([int(v) for v in sys.argv[4].split(",")] if len(sys.argv) >= 5 else (1, 2, 4, 8)):
+    p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1), 0, g)
+    for _ in range(2):
+        r.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        r.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    base = base or ms
+    print("G = %d: %.3f ms per frame slice; %.2fx of the whole frame's time; ideal %.3f ms" % (g, ms, base / ms, base / g))
+r.close()
