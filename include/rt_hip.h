@@ -14,9 +14,11 @@
  *     per-pixel sums; rt_hip_resolve_device turns them into the interleaved image.
  *   - The unit of work is one sub-sample column: the samples_in_row samples (sx, 0..S-1) of one pixel
  *     (the inner loop of ray_tracing/frame.cpp:59-66).  A trace can be restricted to a slice of the
- *     sample space: column sx of pixel p belongs to slice (p * S + sx) % slice_count.  The sums of all
- *     slices add up to the whole frame, which is how one frame is sharded over several GPUs (one
- *     process per GPU; the caller reduces the planes).
+ *     sample space: the samples of the frame, numbered ((p * S + sx) * S + sy) in the order the
+ *     reference's loops visit them, are dealt out to the slices in turn (sample number % slice_count;
+ *     slice_count < 65536), so every slice takes every slice_count-th sample of each column.  The sums
+ *     of all slices add up to the whole frame, which is how one frame is sharded over several GPUs
+ *     (one process per GPU; the caller reduces the planes).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H

@@ -630,8 +630,9 @@ static void * worker(void * arg)
         for (uint32_t sy = 0; sy < s_row; ++sy)
         {
           uint32_t const sample = sx * s_row + sy;
-          /* Sharding (not in the reference): sub-sample column sx of a pixel belongs to one slice. */
-          if (((uint64_t)pixel * s_row + sx) % slices != p->slice_index % slices)
+          /* Sharding (not in the reference): the samples of the frame, numbered (pixel, sx, sy) in this loop
+           * order, are dealt out to the slices in turn. */
+          if ((((uint64_t)pixel * s_row + sx) * s_row + sy) % slices != p->slice_index % slices)
             continue;
           v3 const d = primary_dir(&basis, width, height, s_row, x, y, sx, sy);
           color = add(color, ray_trace(w->scene, w->cam, p, pixel, sample, d, &w->stats));

@@ -87,7 +87,7 @@ typedef struct
   uint32_t flags;
   uint32_t seed;
   uint32_t max_depth;   /* 0 -> ORC_MAX_DEPTH; 1 = primary hit + direct light only */
-  uint32_t slice_index; /* this renderer owns column sx of pixel p iff (p * S + sx) % slice_count == slice_index */
+  uint32_t slice_index; /* this renderer owns sample (sx, sy) of pixel p iff ((p * S + sx) * S + sy) % slice_count == slice_index */
   uint32_t slice_count; /* 0 or 1 -> everything */
 } orc_params;
 

@@ -248,13 +248,15 @@ struct TraceArgs
   f3 grid_org;
   float grid_cell, grid_inv_cell;
   // outputs
-  float * partial;            // this slice's column sums, RGB interleaved, in slice order: item slice_index +
-                              // slice_count * k is entry k (partial[3 * k + c])
+  float * partial;            // per column (item), the sum of the samples this slice owns: partial[3 * item + c]
   uint32_t n_items;           // width * height * s_row
-  uint32_t n_positions;       // columns this slice owns = length of its work queue; position k is column k of the
-                              // slice, item slice_index + slice_count * k of the frame
+  // Slices: the samples of the frame, numbered item * s_row + sy, are dealt out to the slices in turn, so this
+  // slice traces the samples sy = first_sample(item), + slice_count, ... of every column.  The work queue is
+  // the items in order; position k is item k.
   uint32_t * queue_counter;   // next queue position of this slice to hand out
-  uint32_t batch_items;       // queue positions a wave reserves at a time
+  uint32_t batch_items;       // queue positions a wave reserves at a time ...
+  uint32_t batch_min;         // ... and near the end of the queue (see rt_hip.hip ItemPool)
+  uint32_t guide_waves;       // waves of the launch
   const uint32_t * cancel;    // non-zero: stop handing out work (host-visible memory, read on refills only)
   unsigned long long * stats; // counters, see rt_hip.hip
   // Sample sharing at the end of the queue (optional, share_depth = 0: off).  Once a wave finds the queue used
@@ -385,6 +387,16 @@ RT_FN f3 primary_dir(const TraceArgs & A, float sdx, float dyp, uint32_t sy)
   return normalize3((A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * sdx);
 }
 
+// First sample (sy) of column `item` that this slice owns; >= s_row when it owns none.  The owner of sample
+// item * s_row + sy is that number modulo slice_count (slice_count < 65536, so the products below fit).
+RT_FN uint32_t first_sample(const TraceArgs & A, uint32_t item)
+{
+  if (A.slice_count <= 1u)
+    return 0u;
+  uint32_t const at = ((item % A.slice_count) * (A.s_row % A.slice_count)) % A.slice_count;  // owner of sy = 0
+  return (A.slice_index + A.slice_count - at) % A.slice_count;
+}
+
 RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
 {
   uint32_t const pixel = item / A.s_row;
@@ -393,7 +405,7 @@ RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
   uint32_t const x = pixel - y * A.width;
   L.pixel = pixel;
   L.sx = sx;
-  L.sy = 0;
+  L.sy = first_sample(A, item);
   L.sy_end = A.s_row;
   L.dyp = (-2.0f * (float)y / (float)A.height + 1.0f) * A.dh;        // frame.cpp:49
   float const dxp = (2.0f * (float)x / (float)A.width - 1.0f) * A.dw;  // frame.cpp:52
@@ -401,19 +413,26 @@ RT_FN void begin_item(const TraceArgs & A, Lane & L, uint32_t item)
   L.sum = mk3(0.0f, 0.0f, 0.0f);
 }
 
-// Column `slot` of the slice as an item (pixel * s_row + sx) of the frame.
-RT_FN uint32_t slice_item(const TraceArgs & A, uint32_t slot) { return A.slice_index + A.slice_count * slot; }
-
 // Samples a lane can share out right now (see TraceArgs::shared): those of its own column it has not started,
 // less the one it is about to start, and only the last share_depth of the column.
 RT_FN uint32_t spare_samples(const TraceArgs & A, const Lane & L)
 {
   if (!L.alive || L.need_item || (L.slot & RT_SHARED_SLOT) != 0u)
     return 0u;
-  uint32_t const keep = (!L.has_hit && !L.shading) ? 1u : 0u;
+  // the lane's samples are sy, sy + slice_count, ... below sy_end
+  uint32_t from = L.sy + ((!L.has_hit && !L.shading) ? A.slice_count : 0u);
   uint32_t const first_shareable = (A.s_row > A.share_depth) ? A.s_row - A.share_depth : 0u;
-  uint32_t const from = (L.sy + keep > first_shareable) ? L.sy + keep : first_shareable;
-  return (L.sy_end > from) ? L.sy_end - from : 0u;
+  if (from < first_shareable)
+    from += (first_shareable - from + A.slice_count - 1u) / A.slice_count * A.slice_count;
+  return (L.sy_end > from) ? (L.sy_end - from + A.slice_count - 1u) / A.slice_count : 0u;
+}
+
+// The j-th last of `spare` spare samples of a lane whose samples end below sy_end and start at `from` (as in
+// spare_samples): the owner keeps everything below the smallest one handed out.
+RT_FN uint32_t spare_sample_sy(const TraceArgs & A, uint32_t sy, uint32_t sy_end, uint32_t j)
+{
+  uint32_t const last = sy + (sy_end - 1u - sy) / A.slice_count * A.slice_count;  // the lane's last sample
+  return last - j * A.slice_count;
 }
 
 // Makes an idle lane trace sample sy of the column another lane owns (the owner's ray set-up is passed in).
@@ -437,12 +456,13 @@ RT_FN void take_shared_sample(const TraceArgs & A, Lane & L, uint32_t region_bas
 }
 
 // Completes the sum of a column whose last samples were traced by other lanes: the owner's partial sum, then
-// the shared colours in increasing sy, the additions the owner would have made itself.
-RT_FN void fold_split(float * partial, const float * shared, u4 rec, uint32_t s_row)
+// the shared colours in increasing sy (every step-th sample from the first shared one), the additions the owner
+// would have made itself.
+RT_FN void fold_split(float * partial, const float * shared, u4 rec, uint32_t s_row, uint32_t step)
 {
   float * const c = partial + 3u * (size_t)rec.x;
   f3 sum = mk3(c[0], c[1], c[2]);
-  for (uint32_t sy = rec.y; sy < s_row; ++sy)
+  for (uint32_t sy = rec.y; sy < s_row; sy += step)
   {
     const float * const v = shared + 3u * (size_t)(rec.z + (s_row - 1u - sy));
     sum = sum + mk3(v[0], v[1], v[2]);
@@ -457,14 +477,14 @@ struct ItemInfo
   uint32_t pos;           // queue position; RT_INVALID: the slice is used up
   bool prepared;
   float sdx, dyp;
-  uint32_t cm0, cm1, pixel, sx;
+  uint32_t cm0, cm1, pixel, sx, sy0;
   uint32_t filter_tests;  // columns this lane ran through the filter while preparing a batch (for anyone)
 };
 
 struct ColumnEntry
 {
   float sdx, dyp;
-  uint32_t cm0, cm1, pixel, sx, pad0, pad1;
+  uint32_t cm0, cm1, pixel, sx, sy0, pad;  // sy0: first_sample of the column
 };
 
 // Filter of one ray against `count` (<= RT_CHUNK) camera-table entries; defined below.
@@ -492,7 +512,8 @@ RT_FN ColumnEntry prepare_column(const TraceArgs & A, const f4 * camtab, uint32_
   uint32_t const c0 = (A.n_padded < RT_CHUNK) ? A.n_padded : RT_CHUNK;
   e.cm0 = filter_chunk_1(camtab, c0, dc);
   e.cm1 = (A.n_padded > RT_CHUNK) ? filter_chunk_1(camtab + RT_CHUNK, A.n_padded - RT_CHUNK, dc) : 0u;
-  e.pad0 = e.pad1 = 0u;
+  e.sy0 = first_sample(A, item);
+  e.pad = 0u;
   return e;
 }
 
@@ -1077,7 +1098,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             {
               L.pixel = info.pixel;
               L.sx = info.sx;
-              L.sy = 0;
+              L.sy = info.sy0;
               L.sy_end = A.s_row;
               L.sdx = info.sdx;
               L.dyp = info.dyp;
@@ -1086,7 +1107,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
               L.sum = mk3(0.0f, 0.0f, 0.0f);
             }
             else
-              begin_item(A, L, slice_item(A, L.slot));
+              begin_item(A, L, L.slot);
             L.need_item = false;
           }
         }
@@ -1094,7 +1115,9 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       // The queue is used up for this wave: idle lanes take samples off the busy lanes' columns.
       if (env.endgame())
         env.share(L);
-      bool const active = L.alive && !L.has_hit && !L.shading;  // a lane that asked has its item, or is idle now
+      // (a lane that asked has its item, or is idle now; a column of which the slice owns no sample is completed
+      // in the next round)
+      bool const active = L.alive && !L.has_hit && !L.shading && L.sy < L.sy_end;
       RT_REGION(cnt, 0);
       if (env.any(active))
       {
@@ -1103,7 +1126,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         if (active)
         {
           d = primary_dir(A, L.sdx, L.dyp, L.sy);
-          L.sy += 1;
+          L.sy += A.slice_count;
         }
         float const a = dot3(d, d);
         float t;

@@ -58,7 +58,7 @@ constexpr uint32_t kStatsWords = 8;
 // multiple of kItemBatch chosen by the host: a single counter word sustains well under a hundred reservations
 // per microsecond, far fewer than the waves would ask for item by item, or even batch by batch when columns
 // are short).  The wave works through its reservation in windows of kItemBatch, serving its lanes from the
-// window with a ballot and a prefix count.  Position k of the queue is column k of the slice.
+// window with a ballot and a prefix count.  Position k of the queue is item k (every slice visits every column).
 #if defined(RT_PROFILE_REGIONS)
 // Per wave of the resident kernel: constant-rate clock (100 MHz) at entry, after staging, after the loop, and when the
 // wave found the queue used up.
@@ -73,12 +73,14 @@ __device__ __forceinline__ void timeline_mark(uint32_t k)
 #endif
 constexpr uint32_t kItemBatch = 64;
 constexpr uint32_t kCancelPoll = 8;
+constexpr uint32_t kGuide = 16;
 
 struct ItemPool
 {
   uint32_t next = 0, end = 0;  // the current window, wave-uniform
   uint32_t reserved_end = 0;   // end of the wave's reservation
   uint32_t refills = 0;
+  uint32_t last_size = 0;      // size of the wave's previous reservation
   bool exhausted = false;      // the last reservation lay past the end of the queue: nothing more will come
 
   // Opens the next window: the rest of the reservation, or a new reservation.
@@ -86,6 +88,21 @@ struct ItemPool
   {
     if (end == reserved_end)
     {
+      // Reservations shrink towards the end of the queue (down to batch_min), so that the waves run dry within
+      // a short reservation of each other: a wave takes 1 / (kGuide * waves) of what it believes is left, a
+      // fraction small enough that a reservation in the most expensive part of the frame (several times the
+      // average cost per sample) is still worked off before the others have emptied the queue.  It does
+      // not read the counter for that (every wave reading the word the others add to costs more than it gains):
+      // it reckons that since its own last reservation every wave made one more of the same size.
+      uint32_t size = A.batch_items;
+      if (A.batch_min < A.batch_items)
+      {
+        unsigned long long const seen = (unsigned long long)reserved_end + (unsigned long long)A.guide_waves * last_size;
+        unsigned long long const left = seen < A.n_items ? A.n_items - seen : 0ull;
+        unsigned long long const want = left / ((unsigned long long)kGuide * A.guide_waves) / kItemBatch * kItemBatch;
+        size = (uint32_t)min(max(want, (unsigned long long)A.batch_min), (unsigned long long)A.batch_items);
+      }
+      last_size = size;
       uint32_t base = 0;
       if (__lane_id() == 0)
       {
@@ -94,12 +111,12 @@ struct ItemPool
         bool cancelled = false;
         if ((refills % kCancelPoll) == 0u)
           cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-        base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, A.batch_items);
+        base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, size);
       }
       refills += 1u;
       end = __builtin_amdgcn_readfirstlane(base);
-      reserved_end = end + A.batch_items;
-      exhausted = end >= A.n_positions;
+      reserved_end = end + size;
+      exhausted = end >= A.n_items;
 #if defined(RT_PROFILE_REGIONS)
       if (exhausted)
         timeline_mark(3);
@@ -130,7 +147,7 @@ struct ItemPool
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (need && rank < avail)
       {
-        result = (next + rank < A.n_positions) ? next + rank : RT_INVALID;
+        result = (next + rank < A.n_items) ? next + rank : RT_INVALID;
         need = false;
       }
       next += wanted < avail ? wanted : avail;
@@ -175,15 +192,15 @@ __device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L)
     uint32_t const d = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(donors));
     donors &= donors - 1ull;
     uint32_t const give = min(min(lane_value(spare, d), per), n_idle - taken);
-    uint32_t const d_end = lane_value(L.sy_end, d);
+    uint32_t const d_end = lane_value(L.sy_end, d), d_sy = lane_value(L.sy, d);
     uint32_t const d_pixel = lane_value(L.pixel, d), d_sx = lane_value(L.sx, d);
     uint32_t const d_cm0 = lane_value(L.cm0, d), d_cm1 = lane_value(L.cm1, d);
     float const d_sdx = lane_value(L.sdx, d), d_dyp = lane_value(L.dyp, d);
     if (lane == d)
-      L.sy_end = d_end - give;
+      L.sy_end = spare_sample_sy(A, d_sy, d_end, give - 1u);  // the owner keeps what lies below
     if (was_idle && my_rank >= taken && my_rank < taken + give)
       take_shared_sample(A, L, (wave_first + d) * A.share_depth, d_pixel, d_sx, d_sdx, d_dyp, d_cm0, d_cm1,
-                         d_end - 1u - (my_rank - taken));
+                         spare_sample_sy(A, d_sy, d_end, my_rank - taken));
     taken += give;
   }
 }
@@ -256,9 +273,9 @@ struct WaveEnv
         pool.refill(A);
         ColumnEntry e;
         e.pixel = RT_INVALID;
-        if (pool.next + lane < A.n_positions)
+        if (pool.next + lane < A.n_items)
         {
-          e = prepare_column(A, cam, slice_item(A, pool.next + lane));
+          e = prepare_column(A, cam, pool.next + lane);
           info.filter_tests += 1u;
         }
         batch[lane] = e;
@@ -280,6 +297,7 @@ struct WaveEnv
           info.cm1 = e.cm1;
           info.pixel = e.pixel;
           info.sx = e.sx;
+          info.sy0 = e.sy0;
         }
         need = false;
       }
@@ -504,55 +522,46 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
 // lane per record; the records of a launch are at most one per lane of its grid.
 __global__ __launch_bounds__(256) void fold_kernel(float * __restrict__ partial, const float * __restrict__ shared,
                                                    const u4 * __restrict__ splits,
-                                                   const uint32_t * __restrict__ split_count, uint32_t s_row)
+                                                   const uint32_t * __restrict__ split_count, uint32_t s_row,
+                                                   uint32_t slice_count)
 {
   uint32_t const n = *split_count;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    fold_split(partial, shared, splits[i], s_row);
+    fold_split(partial, shared, splits[i], s_row, slice_count);
 }
 
-// The accumulate pass: per pixel, the column sums this slice owns are added in increasing sx (the order
-// Frame::ForEachRayImpl adds its outer loop, ray_tracing/frame.cpp:56).  partial holds the slice's column sums
-// (interleaved RGB) in slice order, so the columns a pixel owns are consecutive entries; planes: 3 planes of n
-// floats.  One lane per pixel.
+// The accumulate pass: per pixel, the column sums are added in increasing sx (the order Frame::ForEachRayImpl
+// adds its outer loop, ray_tracing/frame.cpp:56).  partial: the column sums (interleaved RGB), s_row consecutive
+// entries per pixel; planes: 3 planes of n floats.  One lane per pixel.
 __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ partial, float * __restrict__ planes,
-                                                     uint32_t n, uint32_t s_row, uint32_t slice_index,
-                                                     uint32_t slice_count)
+                                                     uint32_t n, uint32_t s_row)
 {
   uint32_t const stride = gridDim.x * blockDim.x;
-  bool const wide = (s_row % slice_count) == 0u && ((s_row / slice_count) % 4u) == 0u;
+  bool const wide = (s_row % 4u) == 0u;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
   {
-    unsigned long long const first = (unsigned long long)p * s_row;
-    // first owned column: smallest sx with (first + sx) % slice_count == slice_index
-    uint32_t const sx0 = (uint32_t)((slice_index + slice_count - (uint32_t)(first % slice_count)) % slice_count);
+    const float * c = partial + 3u * (size_t)p * s_row;
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    if (sx0 < s_row)
+    if (wide)
     {
-      size_t const k0 = (size_t)((first + sx0 - slice_index) / slice_count);
-      uint32_t const owned = (s_row - sx0 + slice_count - 1u) / slice_count;
-      const float * c = partial + 3u * k0;
-      if (wide)
+      // a multiple of four columns: 48-byte groups, 16-byte aligned
+      const float4 * v = reinterpret_cast<const float4 *>(c);
+      for (uint32_t i = 0; i < s_row; i += 4u, v += 3)
       {
-        // every pixel owns the same multiple of four columns: 48-byte groups, 16-byte aligned
-        const float4 * v = reinterpret_cast<const float4 *>(c);
-        for (uint32_t i = 0; i < owned; i += 4u, v += 3)
-        {
-          float4 const a0 = v[0], a1 = v[1], a2 = v[2];
-          r += a0.x; g += a0.y; b += a0.z;
-          r += a0.w; g += a1.x; b += a1.y;
-          r += a1.z; g += a1.w; b += a2.x;
-          r += a2.y; g += a2.z; b += a2.w;
-        }
+        float4 const a0 = v[0], a1 = v[1], a2 = v[2];
+        r += a0.x; g += a0.y; b += a0.z;
+        r += a0.w; g += a1.x; b += a1.y;
+        r += a1.z; g += a1.w; b += a2.x;
+        r += a2.y; g += a2.z; b += a2.w;
       }
-      else
-        for (uint32_t i = 0; i < owned; ++i, c += 3)
-        {
-          r += c[0];
-          g += c[1];
-          b += c[2];
-        }
     }
+    else
+      for (uint32_t i = 0; i < s_row; ++i, c += 3)
+      {
+        r += c[0];
+        g += c[1];
+        b += c[2];
+      }
     planes[p] = r;
     planes[n + p] = g;
     planes[2u * (size_t)n + p] = b;
@@ -745,12 +754,23 @@ int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long lon
 uint32_t batch_items(const rt_hip_trace_params * p, int compute_units)
 {
   unsigned long long const g = p->slice_count ? p->slice_count : 1u;
-  unsigned long long const items = ((unsigned long long)p->width * p->height * p->samples_in_row + g - 1u) / g;
+  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
+  unsigned long long const per_column = std::max<unsigned long long>(1u, p->samples_in_row / g);  // of this slice
   unsigned long long const waves = (unsigned long long)std::max(compute_units, 1) * 4u * kWavesPerSimd;
-  unsigned long long k = (1024u + kItemBatch * p->samples_in_row - 1u) / (kItemBatch * p->samples_in_row);
+  unsigned long long k = (1024u + kItemBatch * per_column - 1u) / (kItemBatch * per_column);
   unsigned long long const balance = items / (waves * kItemBatch * 4u);
   k = std::max<unsigned long long>(1u, std::min(k, balance));
   return (uint32_t)(k * kItemBatch);
+}
+
+// Smallest reservation near the end of the queue: about 256 samples' worth (the counter word stays well below
+// its limit even if every reservation were that small), at least one window.
+uint32_t batch_min(const rt_hip_trace_params * p, uint32_t batch)
+{
+  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
+  unsigned long long const per_column = std::max<unsigned long long>(1u, p->samples_in_row / g);
+  unsigned long long const k = (256u + kItemBatch * per_column - 1u) / (kItemBatch * per_column);
+  return (uint32_t)std::min<unsigned long long>(k * kItemBatch, batch);
 }
 
 // The end of a launch: a wave that finds the queue used up spreads the samples its busy lanes have not started
@@ -760,29 +780,20 @@ uint32_t batch_items(const rt_hip_trace_params * p, int compute_units)
 constexpr uint32_t kShareDepth = 64;
 uint32_t share_depth(const rt_hip_trace_params * p) { return std::min(p->samples_in_row, kShareDepth); }
 size_t share_bytes_for(size_t lanes, uint32_t depth) { return 16u + lanes * (sizeof(u4) + 3u * sizeof(float) * depth); }
-unsigned long long slice_columns(const rt_hip_trace_params * p)
+unsigned long long frame_items(const rt_hip_trace_params * p)
 {
-  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
-  unsigned long long const r = p->slice_count ? p->slice_index : 0u;
-  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
-  return (items > r) ? (items - r + g - 1u) / g : 0u;
+  return (unsigned long long)p->width * p->height * p->samples_in_row;
 }
 // Enough for any grid this frame can be traced with.
 size_t share_bytes(const rt_hip_trace_params * p)
 {
-  unsigned long long const columns = slice_columns(p);
   unsigned long long const chip = (unsigned long long)std::max(g_lib.compute_units, 1) * 4u * kWavesPerSimdForward * 64u;
-  size_t const lanes = (size_t)std::min(chip, (columns + kBlock - 1u) / kBlock * kBlock);
+  size_t const lanes = (size_t)std::min(chip, (frame_items(p) + kBlock - 1u) / kBlock * kBlock);
   return share_bytes_for(lanes, share_depth(p));
 }
 
-// Column sums of one slice: 12 bytes per owned column.
-size_t partial_bytes(const rt_hip_trace_params * p)
-{
-  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
-  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
-  return 3 * sizeof(float) * (size_t)((items + g - 1u) / g);
-}
+// Column sums: 12 bytes per column of the frame, whatever the slice (every slice visits every column).
+size_t partial_bytes(const rt_hip_trace_params * p) { return 3 * sizeof(float) * (size_t)frame_items(p); }
 
 // A trace's output buffer: the column sums, then (256-byte aligned) the room sample sharing needs.
 size_t trace_buffer_bytes(const rt_hip_trace_params * p)
@@ -806,6 +817,8 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
     return fail(RT_HIP_ERR_INVALID, "width * height * samples_in_row must stay below 0xF0000000");
   if (p->slice_count > 1u && p->slice_index >= p->slice_count)
     return fail(RT_HIP_ERR_INVALID, "slice_index must be below slice_count");
+  if (p->slice_count > 65535u)
+    return fail(RT_HIP_ERR_INVALID, "slice_count must stay below 65536");
   return RT_HIP_OK;
 }
 
@@ -840,6 +853,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
   a.batch_items = batch_items(p, g_lib.compute_units);
+  a.batch_min = batch_min(p, a.batch_items);
 
   RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
   if (uses_grid(scene, p->flags))
@@ -863,10 +877,9 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
                        scene->n_padded, a.cam_pos, a.col_delta);
     RT_CHECK(hipGetLastError());
   }
-  unsigned long long const my_items = slice_columns(p);
-  int const blocks = persistent_blocks(scene, p->flags, my_items, d_cancel != nullptr);
+  int const blocks = persistent_blocks(scene, p->flags, a.n_items, d_cancel != nullptr);
+  a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   size_t const lds = lds_bytes(scene, p->flags);
-  a.n_positions = (uint32_t)my_items;
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
   size_t const lanes = (size_t)blocks * kBlock;
   size_t const share_at = (partial_bytes(p) + 255u) & ~(size_t)255u;
@@ -889,7 +902,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   if (a.share_depth != 0u)
   {
     hipLaunchKernelGGL(fold_kernel, dim3(std::min(blocks, 256)), dim3(256), 0, stream, d_partial, a.shared, a.splits,
-                       a.split_count, a.s_row);
+                       a.split_count, a.s_row, a.slice_count);
     RT_CHECK(hipGetLastError());
   }
   if (ev_stop)
@@ -900,10 +913,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
 int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream)
 {
   uint32_t const n = p->width * p->height;
-  uint32_t const g = p->slice_count ? p->slice_count : 1u;
   int const blocks = (int)std::min<uint32_t>((n + 255u) / 256u, 256u * 8u);
-  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row,
-                     p->slice_index % g, g);
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row);
   RT_CHECK(hipGetLastError());
   return RT_HIP_OK;
 }

@@ -40,8 +40,9 @@ struct HostEnv
       // a varying number, so that columns are cut at different places (and some not at all)
       uint32_t const give = (L.pixel + L.sx) % (spare + 1u);
       for (uint32_t j = 0; j < give; ++j)
-        waiting.push_back({region_base, L.pixel, L.sx, L.cm0, L.cm1, L.sy_end - 1u - j, L.sdx, L.dyp});
-      L.sy_end -= give;
+        waiting.push_back({region_base, L.pixel, L.sx, L.cm0, L.cm1, rtc::spare_sample_sy(A, L.sy, L.sy_end, j), L.sdx, L.dyp});
+      if (give != 0u)
+        L.sy_end = rtc::spare_sample_sy(A, L.sy, L.sy_end, give - 1u);
     }
     else if (!L.alive && !waiting.empty())
     {
@@ -63,12 +64,12 @@ struct HostEnv
     info.pos = rtc::RT_INVALID;
     info.prepared = false;
     info.filter_tests = 0;
-    if (!need || next >= A.n_positions)
+    if (!need || next >= A.n_items)
       return;
     info.pos = next++;
     if (A.column_masks != 0u)
     {
-      rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, rtc::slice_item(A, info.pos));
+      rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, info.pos);
       info.prepared = true;
       info.sdx = e.sdx;
       info.dyp = e.dyp;
@@ -76,6 +77,7 @@ struct HostEnv
       info.cm1 = e.cm1;
       info.pixel = e.pixel;
       info.sx = e.sx;
+      info.sy0 = e.sy0;
       info.filter_tests = 1;
     }
   }
@@ -167,9 +169,6 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   std::vector<rtc::f4> stack(rtc::RT_MAX_DEPTH);
   rtc::LaneCounters cnt{};
   HostEnv env{a, a.n_items, (tile_size && !column_masks) ? tile_size : (padded ? padded : 4u)};
-  uint32_t const slice_columns =
-      (a.n_items > a.slice_index) ? (a.n_items - a.slice_index + a.slice_count - 1u) / a.slice_count : 0u;
-  a.n_positions = slice_columns;
   std::vector<float> shared;
   if ((mode & 8u) != 0u)
   {
@@ -205,19 +204,18 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
 
   g_last_split_count = (unsigned long long)env.splits.size();
   for (rtc::u4 const & rec : env.splits)
-    rtc::fold_split(partial.data(), shared.data(), rec, s_row);
+    rtc::fold_split(partial.data(), shared.data(), rec, s_row, a.slice_count);
   if (env.share_test && !env.waiting.empty())
     return 4;
 
-  // accumulate (owned columns in increasing sx) + resolve, as colsum_kernel and resolve_kernel do
+  // accumulate (columns in increasing sx) + resolve, as colsum_kernel and resolve_kernel do
   float const inv = 1.0f / static_cast<float>(s_row * s_row);
   for (uint32_t i = 0; i < np; ++i)
     for (uint32_t c = 0; c < 3; ++c)
     {
       float sum = 0.0f;
       for (uint32_t sx = 0; sx < s_row; ++sx)
-        if (((unsigned long long)i * s_row + sx) % a.slice_count == a.slice_index)
-          sum += partial[3u * (size_t)(((unsigned long long)i * s_row + sx - a.slice_index) / a.slice_count) + c];
+        sum += partial[3u * ((size_t)i * s_row + sx) + c];
       rgb[3u * (size_t)i + c] = sum * inv;
     }
   if (stats6)

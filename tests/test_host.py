@@ -68,7 +68,8 @@ def test_sharding_rule():
     from rt_amd import sharding
 
     for s_row, count in ((2, 8), (16, 8), (3, 2), (10, 4)):
-        owners = [sharding.owner_of(p, sx, s_row, count) for p in range(64) for sx in range(s_row)]
+        owners = [sharding.owner_of(p, sx, sy, s_row, count) for p in range(64) for sx in range(s_row)
+                  for sy in range(s_row)]
         per = np.bincount(owners, minlength=count)
         assert per.max() - per.min() <= 1  # balanced whatever divides what
 
