@@ -232,6 +232,7 @@ struct TraceArgs
   // frame
   uint32_t width, height, s_row, s_count;  // s_count = s_row * s_row
   uint32_t flags, seed, max_depth, slice_index, slice_count;
+  uint32_t s_row_mod;  // s_row % slice_count
   // Column masks (small resident scenes): the primary-ray filter runs once per sub-sample column, against the
   // column's middle direction, with every bound of the camera table lowered by |centre - camera| * col_delta;
   // col_delta bounds the distance between the middle direction and any sample direction of a column.
@@ -377,7 +378,6 @@ struct Lane
   float e, m_refraction, s_a;
   float nx_t;
   int nx_i;  // nearest hit of the scattered ray (found during the first light's pass)
-  u4 shadow_words;  // Philox block of the first light's shadow jitter, drawn with the scatter block
 };
 
 // Frame::ForEachRayImpl, ray_tracing/frame.cpp:61-62: direction of sub-sample (sx, sy) given the column's sdx.
@@ -391,9 +391,9 @@ RT_FN f3 primary_dir(const TraceArgs & A, float sdx, float dyp, uint32_t sy)
 // item * s_row + sy is that number modulo slice_count (slice_count < 65536, so the products below fit).
 RT_FN uint32_t first_sample(const TraceArgs & A, uint32_t item)
 {
-  if (A.slice_count <= 1u)
-    return 0u;
-  uint32_t const at = ((item % A.slice_count) * (A.s_row % A.slice_count)) % A.slice_count;  // owner of sy = 0
+  if (A.s_row_mod == 0u)
+    return A.slice_index;  // slice_count divides s_row (or is 1): the same samples of every column
+  uint32_t const at = ((item % A.slice_count) * A.s_row_mod) % A.slice_count;  // owner of sy = 0
   return (A.slice_index + A.slice_count - at) % A.slice_count;
 }
 
@@ -1033,12 +1033,14 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
   return (rays_on & ~live) & ((1u << RT_LIGHT_SAMPLES) - 1u);
 }
 
-template <bool kForward, bool kGrid, class Env>
+// kOneLight: the scene has exactly one light, so a hit is shaded within one trip (one pass) and nothing of
+// the shading state is carried from trip to trip -- some twenty registers fewer across the loop.
+template <bool kForward, bool kGrid, bool kOneLight, class Env>
 RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t stride, LaneCounters & cnt)
 {
+  uint32_t const n_lights = kOneLight ? 1u : A.n_lights;
   Lane L;
   L.cm0 = L.cm1 = 0u;
-  L.shadow_words.x = L.shadow_words.y = L.shadow_words.z = L.shadow_words.w = 0u;
   L.acc_l = mk3(0.0f, 0.0f, 0.0f);
   L.acc_e = 1.0f;
   L.alive = true;
@@ -1172,6 +1174,10 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     float a[RT_RAYS];
     uint32_t rays_on = 0;
     float w[RT_LIGHT_SAMPLES];
+    // Philox block of the first light's shadow jitter, drawn with the scatter block (the first light's pass is
+    // always in the trip that shades the new hit)
+    u4 shadow_words;
+    shadow_words.x = shadow_words.y = shadow_words.z = shadow_words.w = 0u;
 
     if (L.alive && L.has_hit)
     {
@@ -1199,7 +1205,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         // The first light's shadow block is drawn here too: the two Philox chains are independent and
         // interleave, where each alone is a long run of dependent instructions.
         u4 const rw = philox4x32_10(L.depth, 0u, L.sample, 0u, L.pixel, A.seed);
-        L.shadow_words = philox4x32_10(L.depth, 1u, L.sample, 0u, L.pixel, A.seed);
+        shadow_words = philox4x32_10(L.depth, 1u, L.sample, 0u, L.pixel, A.seed);
         ball = ball3(1.0f, uniform24(rw.x), uniform24(rw.y), uniform24(rw.z));
         xi = uniform24(rw.w);
       }
@@ -1215,7 +1221,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       else
       {
         L.spec = mk3(0.0f, 0.0f, 0.0f);
-        for (uint32_t li = 0; li < A.n_lights; ++li)
+        for (uint32_t li = 0; li < n_lights; ++li)
         {
           f4 const l0 = env.light(li, 0u);
           f4 const l1 = env.light(li, 1u);
@@ -1235,11 +1241,11 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     // The ray set-up below runs for every lane, in a pass or not: lanes that are not compute throw-away rays
     // from their stale (always initialised) state, and rays_on keeps those rays out of the trace.  That is
     // cheaper than a divergent region whose results must be merged with defaults.
-    bool const lit = in_pass && L.li < A.n_lights;
+    bool const lit = in_pass && L.li < n_lights;
     {
-      uint32_t const li_c = (L.li < A.n_lights) ? L.li : 0u;
+      uint32_t const li_c = (L.li < n_lights) ? L.li : 0u;
       f3 to_light = mk3(0.0f, 1.0f, 0.0f);
-      if (A.n_lights != 0u)
+      if (n_lights != 0u)
       {
         f4 const l0 = env.light(li_c, 0u);
         to_light = mk3(-l0.x, -l0.y, -l0.z);
@@ -1262,7 +1268,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       else
       {
         // 15 cells of 8 bits from one Philox block: bytes b[0..15], ball j takes b[3j..3j+2].
-        u4 p0 = L.shadow_words;
+        u4 p0 = shadow_words;
         if (lit && L.li != 0u)
           p0 = philox4x32_10(L.depth, 1u + L.li, L.sample, 0u, L.pixel, A.seed);
         uint32_t const wd[4] = {p0.x, p0.y, p0.z, p0.w};
@@ -1298,7 +1304,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 
     if (in_pass)
     {
-      if (L.li < A.n_lights)
+      if (L.li < n_lights)
       {
         // DirectionalLight::TraceLight, ray_tracing/directional_light.cpp:15-35.
         f4 const l1 = env.light(L.li, 1u);
@@ -1326,7 +1332,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         L.nx_t = near_t;
       }
       L.li += 1;
-      if (L.li >= A.n_lights)
+      if (L.li >= n_lights)
       {
         // l = attenuation + diffuse + specular (demos/demo_frame_cpu.cpp:66); every material's
         // attenuation is its albedo (ray_tracing/default_materials.cpp:14,26,40).
@@ -1356,6 +1362,18 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       }
     }
     RT_REGION(cnt, 10);
+    if constexpr (kOneLight)
+    {
+      // the pass above finished whatever was being shaded: the state it used is dead, say so
+      L.spec = L.diffuse = L.sdir = L.m_albedo = mk3(0.0f, 0.0f, 0.0f);
+      L.e = 0.0f;
+      L.m_refraction = 0.0f;
+      L.s_a = 1.0f;
+      L.nx_t = 0.0f;
+      L.nx_i = -1;
+      L.li = 0;
+      L.shading = false;
+    }
   }
 }
 }  // namespace rtc

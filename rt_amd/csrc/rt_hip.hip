@@ -426,7 +426,7 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
 
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
-template <bool kTiled, bool kForward>
+template <bool kTiled, bool kForward, bool kOneLight>
 __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   {
     __syncthreads();
     BlockEnv env{A, sph, jitter, ItemPool()};
-    trace_loop<kForward, false>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
   {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     timeline_mark(1);
 #endif
     WaveEnv env{A, sph, cam, exact, mats, lights, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
-    trace_loop<kForward, false>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
 #endif
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 
 // The same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).  LDS: [path stacks, unless
 // kForward][jitter table].
-template <bool kForward>
+template <bool kForward, bool kOneLight>
 __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel_grid(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
   cnt.last_tick = __builtin_amdgcn_s_memtime();
 #endif
   GridEnv env{A, jitter, ItemPool()};
-  trace_loop<kForward, true>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+  trace_loop<kForward, true, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   flush_counters(A, cnt);
 }
 
@@ -718,15 +718,23 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
   return std::max<size_t>(bytes, 16u);
 }
 
+// The kernel for a scene: resident / tiled / grid walk, stack or forward accumulation; the forward kernels of
+// the resident and the grid path also come specialised for scenes with exactly one light.
 template <class Launch>
 auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
 {
+  bool const one = sc->n_lights == 1u;
   if (uses_grid(sc, flags))
-    return sc->forward_ok ? go(trace_kernel_grid<true>) : go(trace_kernel_grid<false>);
-  bool const tiled = is_tiled(sc);
-  if (tiled)
-    return sc->forward_ok ? go(trace_kernel<true, true>) : go(trace_kernel<true, false>);
-  return sc->forward_ok ? go(trace_kernel<false, true>) : go(trace_kernel<false, false>);
+  {
+    if (!sc->forward_ok)
+      return go(trace_kernel_grid<false, false>);
+    return one ? go(trace_kernel_grid<true, true>) : go(trace_kernel_grid<true, false>);
+  }
+  if (is_tiled(sc))
+    return sc->forward_ok ? go(trace_kernel<true, true, false>) : go(trace_kernel<true, false, false>);
+  if (!sc->forward_ok)
+    return go(trace_kernel<false, false, false>);
+  return one ? go(trace_kernel<false, true, true>) : go(trace_kernel<false, true, false>);
 }
 
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no

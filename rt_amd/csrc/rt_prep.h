@@ -39,6 +39,7 @@ inline void prepare_frame(const rt_hip_camera & cam, const rt_hip_trace_params &
   a.max_depth = (p.max_depth == 0u || p.max_depth > RT_MAX_DEPTH) ? RT_MAX_DEPTH : p.max_depth;
   a.slice_count = p.slice_count ? p.slice_count : 1u;
   a.slice_index = p.slice_index % a.slice_count;
+  a.s_row_mod = p.samples_in_row % a.slice_count;
 }
 
 // Bound on |D_s - D_c| between the direction through the middle of a sub-sample column and the direction of

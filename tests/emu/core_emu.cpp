@@ -101,7 +101,8 @@ struct HostEnv
 
 // tile_size: records per staged tile (exercises the multi-tile path when smaller than the scene).
 // mode: bit 0 = column masks (scenes of at most 64 spheres, one tile), bit 1 = forward accumulation,
-// bit 2 = rays walk the uniform grid, bit 3 = sample-sharing test mode (see HostEnv).
+// bit 2 = rays walk the uniform grid, bit 3 = sample-sharing test mode (see HostEnv), bit 4 = the general loop
+// even for a scene with one light.
 extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                                const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                                const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
@@ -177,6 +178,9 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     shared.assign(3u * (size_t)a.n_items * a.share_depth, 0.0f);
     a.shared = shared.data();
   }
+  // the forward-accumulating loop comes specialised for one light, as in the library (mode bit 4 keeps the
+  // general loop for such scenes)
+  bool const one_light = l == 1u && (mode & 16u) == 0u;
   rtc::GridHost grid;
   if ((mode & 4u) != 0u)
   {
@@ -192,15 +196,19 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     a.grid_org = rtc::mk3(grid.org[0], grid.org[1], grid.org[2]);
     a.grid_cell = grid.cell;
     a.grid_inv_cell = 1.0f / grid.cell;
-    if ((mode & 2u) != 0u)
-      rtc::trace_loop<true, true>(a, env, stack.data(), 1u, cnt);
+    if ((mode & 2u) != 0u && one_light)
+      rtc::trace_loop<true, true, true>(a, env, stack.data(), 1u, cnt);
+    else if ((mode & 2u) != 0u)
+      rtc::trace_loop<true, true, false>(a, env, stack.data(), 1u, cnt);
     else
-      rtc::trace_loop<false, true>(a, env, stack.data(), 1u, cnt);
+      rtc::trace_loop<false, true, false>(a, env, stack.data(), 1u, cnt);
   }
+  else if ((mode & 2u) != 0u && one_light)
+    rtc::trace_loop<true, false, true>(a, env, stack.data(), 1u, cnt);
   else if ((mode & 2u) != 0u)
-    rtc::trace_loop<true, false>(a, env, stack.data(), 1u, cnt);
+    rtc::trace_loop<true, false, false>(a, env, stack.data(), 1u, cnt);
   else
-    rtc::trace_loop<false, false>(a, env, stack.data(), 1u, cnt);
+    rtc::trace_loop<false, false, false>(a, env, stack.data(), 1u, cnt);
 
   g_last_split_count = (unsigned long long)env.splits.size();
   for (rtc::u4 const & rec : env.splits)

@@ -70,6 +70,19 @@ def test_shared_samples_leave_every_bit_of_the_frame_alone(ffi, scenes, column_m
             assert sa[key] == sb[key], key
 
 
+@pytest.mark.parametrize("demo,spheres,grid", [(1, 0, False), (2, 0, False), (3, 300, True)])
+def test_one_light_loop_equals_the_general_loop(ffi, scenes, demo, spheres, grid):
+    """Scenes with one light run a loop that carries no shading state from trip to trip; same frame, bit for bit."""
+    scene = scenes(demo, 1, spheres)
+    assert scene.light_count == 1
+    for flags in (0, ffi.FLAG_DETERMINISTIC):
+        p = ffi.params(48, 36, 3, flags=flags, seed=4)
+        a, sa = emu_ffi.render(scene, p, forward=True, grid=grid, general_lights=True)
+        b, sb = emu_ffi.render(scene, p, forward=True, grid=grid)
+        np.testing.assert_array_equal(a, b)
+        assert sa == sb
+
+
 def test_forward_accumulation_is_refused_when_the_energy_break_can_trigger(ffi):
     rough = ffi.Scene.build([(0.0, 0.0, 2.0, 1.0, 0)], [(1, (0.9, 0.9, 0.9), 0.95, 0.1)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
     assert not emu_ffi.forward_ok(rough)
