@@ -148,6 +148,23 @@ def test_stack_path_equals_forward_accumulation(hip, oracle, ffi, demo, monkeypa
     assert sa.ray_queries == sb.ray_queries == rs.ray_queries
 
 
+@pytest.mark.parametrize("width,height,s,slices", [(64, 48, 80, 1), (160, 120, 5, 3), (320, 240, 16, 8), (96, 72, 2, 8)])
+def test_sample_sharing_changes_no_bit(hip, ffi, scenes, monkeypatch, width, height, s, slices):
+    """At the end of a launch idle lanes trace samples of other lanes' columns and a fold pass completes the sums;
+    RT_HIP_NO_SHARING switches that off.  Same frame, same counters (long columns, strided slices, columns of
+    which a slice owns no sample)."""
+    for demo in (1, 2):
+        scene = scenes(demo)
+        p = ffi.params(width, height, s, seed=6, slice_index=slices - 1, slice_count=slices)
+        shared, ss = hip.render(scene, p)
+        monkeypatch.setenv("RT_HIP_NO_SHARING", "1")
+        plain, sp = hip.render(scene, p)
+        monkeypatch.delenv("RT_HIP_NO_SHARING")
+        np.testing.assert_array_equal(shared, plain)
+        assert (ss.samples, ss.ray_queries, ss.hit_queries, ss.shaded_bounces) == \
+               (sp.samples, sp.ray_queries, sp.hit_queries, sp.shaded_bounces)
+
+
 @pytest.mark.parametrize("slices", [2, 3, 8])
 def test_slices_add_up(hip, oracle, ffi, scenes, slices):
     scene = scenes(1)
