@@ -3,7 +3,10 @@
 
 A step is one whole frame with the scene already resident in HBM: every rank traces its slice of the
 sample space (rt_hip_trace_device), the planar sums are reduced to rank 0 over RCCL, and rank 0 runs the
-resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.
+resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.  With several
+ranks the frames are pipelined one deep: while the planes of frame k are being reduced, every rank already
+traces frame k + 1 into a second set of planes (--sync-reduce waits for each reduce instead); all K frames
+are reduced and resolved inside the timed region.
 
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -98,6 +101,8 @@ def main():
     ap.add_argument("--spheres", type=int, default=10000, help="sphere count of demo 3")
     ap.add_argument("--grid", action="store_true", help="rays walk the scene's uniform grid (scenes of 64+ spheres)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-reduce", action="store_true",
+                    help="wait for the reduce of every frame before tracing the next (default: one frame in flight)")
     ap.add_argument("--rehearse", action="store_true",
                     help="rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
                          "collectives run over gloo on host copies (timings are not meaningful)")
@@ -133,24 +138,37 @@ def main():
     full = ffi.params(w, h, s, seed=1, flags=flags)
 
     device = torch.device("cuda", local_rank)
-    planes = torch.empty(3 * w * h, dtype=torch.float32, device=device)
+    # Two sets of sum planes: frame k + 1 is traced while the planes of frame k are still being reduced.
+    planes = [torch.empty(3 * w * h, dtype=torch.float32, device=device) for _ in range(2)]
     rgb = torch.empty(w * h * 3, dtype=torch.float32, device=device) if rank == 0 else None
     d_stats = torch.zeros(16, dtype=torch.int64, device=device)
     renderer.upload(scene)
+    rehearsing = args.rehearse and distributed
+    host = [torch.empty(3 * w * h, dtype=torch.float32) for _ in range(2)] if rehearsing else None
+
+    def resolve(k, summed):
+        if rehearsing:
+            planes[k % 2].copy_(summed)
+        stream = torch.cuda.current_stream().cuda_stream
+        renderer.resolve_device(planes[k % 2].data_ptr(), rgb.data_ptr(), full, stream)
+
+    pipe = sharding.ReducePipeline(dist, world, host if rehearsing else planes, on_done=resolve, rank=rank)
+    frame = [0]
 
     def step():
+        k = frame[0]
+        frame[0] += 1
+        pipe.acquire(k)
         stream = torch.cuda.current_stream().cuda_stream
-        renderer.trace_device(scene, p, planes.data_ptr(), d_stats.data_ptr(), stream)
-        if args.rehearse and distributed:
-            host = planes.cpu()
-            sharding.reduce_to_root(dist, host, world)
-            planes.copy_(host)
-        else:
-            sharding.reduce_to_root(dist, planes, world)
-        if rank == 0:
-            renderer.resolve_device(planes.data_ptr(), rgb.data_ptr(), full, stream)
+        renderer.trace_device(scene, p, planes[k % 2].data_ptr(), d_stats.data_ptr(), stream)
+        if rehearsing:
+            host[k % 2].copy_(planes[k % 2])
+        pipe.submit(k)
+        if args.sync_reduce:
+            pipe.drain()
 
     def fence():
+        pipe.drain()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -192,7 +210,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(10):
-            renderer.resolve_device(planes.data_ptr(), rgb.data_ptr(), full, stream.cuda_stream)
+            renderer.resolve_device(planes[0].data_ptr(), rgb.data_ptr(), full, stream.cuda_stream)
         e1.record(stream)
         torch.cuda.synchronize()
         resolve_ms = e0.elapsed_time(e1) / 10.0
@@ -215,13 +233,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s %dx%d, %dx%d SSAA, %d spheres, sample columns sharded over %d GPU(s), RCCL sum-reduce"
+                "workload": "%s %dx%d, %dx%d SSAA, %d spheres, samples sharded over %d GPU(s), RCCL sum-reduce"
                             % ({1: "pretty_spheres", 2: "glass_spheres", 3: "synthetic_spheres"}[args.demo], w, h, s, s,
                                scene.sphere_count, world),
                 "scene_seed": 1,
                 "render_seed": 1,
                 "max_depth": 10,
                 "intersection": "uniform grid" if args.grid else "every sphere (LDS-resident or LDS-tiled)",
+                "frames_in_flight": 1 if (args.sync_reduce or world == 1) else 2,
             },
             "mrays_per_s": round(stats["ray_queries"] / (elapsed / args.steps) / 1e6, 1),
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),

@@ -26,3 +26,52 @@ def reduce_to_root(dist, tensor, world_size, root=0):
     if world_size > 1:
         dist.reduce(tensor, dst=root, op=dist.ReduceOp.SUM)
     return tensor
+
+
+class ReducePipeline:
+    """Sum-reduce of successive frames to rank `root`, one frame behind the producer: while the planes of frame
+    k are being reduced, the caller already fills the other buffer with frame k + 1.
+
+        buf = pipe.acquire(k)      # the buffer frame k goes into (its previous reduce has been waited for)
+        ... fill buf ...           # on GPUs: enqueue the trace on the current stream
+        pipe.submit(k)             # starts the reduce of frame k, then retires frame k - 1
+        pipe.drain()               # retires what is still in flight
+
+    Retiring a frame waits for its reduce and, on the root, calls on_done(k, buffer) with the summed planes.
+    With one rank there is nothing to reduce and submit() retires the frame at once.  The collectives are
+    issued in frame order by every rank, as torch.distributed requires.
+    """
+
+    def __init__(self, dist, world_size, buffers, on_done=None, root=0, rank=0):
+        assert len(buffers) >= 2
+        self.dist, self.world, self.buffers, self.on_done, self.root, self.rank = (
+            dist, max(world_size, 1), buffers, on_done, root, rank)
+        self.pending = {}  # frame -> work handle (None when there was nothing to wait for)
+
+    def acquire(self, k):
+        older = k - len(self.buffers)
+        if older in self.pending:
+            self._retire(older)
+        return self.buffers[k % len(self.buffers)]
+
+    def submit(self, k):
+        buf = self.buffers[k % len(self.buffers)]
+        work = None
+        if self.world > 1:
+            work = self.dist.reduce(buf, dst=self.root, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.pending[k] = work
+        if self.world == 1:
+            self._retire(k)
+        elif (k - 1) in self.pending:
+            self._retire(k - 1)
+
+    def drain(self):
+        for k in sorted(self.pending):
+            self._retire(k)
+
+    def _retire(self, k):
+        work = self.pending.pop(k)
+        if work is not None:
+            work.wait()  # on GPUs: makes the current stream wait for the collective
+        if self.on_done is not None and self.rank == self.root:
+            self.on_done(k, self.buffers[k % len(self.buffers)])
