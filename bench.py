@@ -3,10 +3,11 @@
 
 A step is one whole frame with the scene already resident in HBM: every rank traces its slice of the
 sample space (rt_hip_trace_device), the planar sums are reduced to rank 0 over RCCL, and rank 0 runs the
-resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.  With several
-ranks the frames are pipelined one deep: while the planes of frame k are being reduced, every rank already
-traces frame k + 1 into a second set of planes (--sync-reduce waits for each reduce instead); all K frames
-are reduced and resolved inside the timed region.
+resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.  Two frames
+are in flight, on two streams with their own planes: while the planes of frame k are being reduced, every rank
+already traces frame k + 1, whose first waves also take over the compute units that the last waves of frame k
+leave idle (--sync-reduce runs one frame at a time instead); all K frames are reduced and resolved inside
+the timed region, so the value is the throughput of a stream of frames, not the inverse of one frame's latency.
 
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -102,7 +103,7 @@ def main():
     ap.add_argument("--grid", action="store_true", help="rays walk the scene's uniform grid (scenes of 64+ spheres)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-reduce", action="store_true",
-                    help="wait for the reduce of every frame before tracing the next (default: one frame in flight)")
+                    help="one frame at a time on one stream (default: two frames in flight on two streams)")
     ap.add_argument("--rehearse", action="store_true",
                     help="rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
                          "collectives run over gloo on host copies (timings are not meaningful)")
@@ -138,32 +139,43 @@ def main():
     full = ffi.params(w, h, s, seed=1, flags=flags)
 
     device = torch.device("cuda", local_rank)
-    # Two sets of sum planes: frame k + 1 is traced while the planes of frame k are still being reduced.
+    # Two frames in flight, each with its own stream, sum planes, image and counters: frame k + 1 is traced while
+    # the planes of frame k are still being reduced, and its first waves fill the compute units that the last
+    # waves of frame k leave idle (rt_hip_trace_device keeps a workspace per stream).
+    lanes = 1 if args.sync_reduce else 2
+    # (different priorities: HIP then gives the streams hardware queues of their own, without which the second
+    # frame's kernels would simply queue behind the first's)
+    streams = [torch.cuda.Stream(device=device, priority=-(i % 2)) for i in range(lanes)]
     planes = [torch.empty(3 * w * h, dtype=torch.float32, device=device) for _ in range(2)]
-    rgb = torch.empty(w * h * 3, dtype=torch.float32, device=device) if rank == 0 else None
-    d_stats = torch.zeros(16, dtype=torch.int64, device=device)
+    rgbs = [torch.empty(w * h * 3, dtype=torch.float32, device=device) for _ in range(2)] if rank == 0 else None
+    d_stats = [torch.zeros(16, dtype=torch.int64, device=device) for _ in range(2)]
     renderer.upload(scene)
     rehearsing = args.rehearse and distributed
     host = [torch.empty(3 * w * h, dtype=torch.float32) for _ in range(2)] if rehearsing else None
+
+    def on_stream(k):
+        return torch.cuda.stream(streams[k % lanes])
 
     def resolve(k, summed):
         if rehearsing:
             planes[k % 2].copy_(summed)
         stream = torch.cuda.current_stream().cuda_stream
-        renderer.resolve_device(planes[k % 2].data_ptr(), rgb.data_ptr(), full, stream)
+        renderer.resolve_device(planes[k % 2].data_ptr(), rgbs[k % 2].data_ptr(), full, stream)
 
-    pipe = sharding.ReducePipeline(dist, world, host if rehearsing else planes, on_done=resolve, rank=rank)
+    pipe = sharding.ReducePipeline(dist, world, host if rehearsing else planes, on_done=resolve, rank=rank,
+                                   context=on_stream)
     frame = [0]
 
     def step():
         k = frame[0]
         frame[0] += 1
         pipe.acquire(k)
-        stream = torch.cuda.current_stream().cuda_stream
-        renderer.trace_device(scene, p, planes[k % 2].data_ptr(), d_stats.data_ptr(), stream)
-        if rehearsing:
-            host[k % 2].copy_(planes[k % 2])
-        pipe.submit(k)
+        with on_stream(k):
+            stream = torch.cuda.current_stream().cuda_stream
+            renderer.trace_device(scene, p, planes[k % 2].data_ptr(), d_stats[k % 2].data_ptr(), stream)
+            if rehearsing:
+                host[k % 2].copy_(planes[k % 2])
+            pipe.submit(k)
         if args.sync_reduce:
             pipe.drain()
 
@@ -187,7 +199,7 @@ def main():
         elapsed = float(t.item())
 
     # counters of this rank's last trace, summed over ranks
-    counters = d_stats[:8].clone()
+    counters = d_stats[0][:8].clone()
     if distributed:
         if args.rehearse:
             counters = counters.cpu()
@@ -210,7 +222,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(10):
-            renderer.resolve_device(planes[0].data_ptr(), rgb.data_ptr(), full, stream.cuda_stream)
+            renderer.resolve_device(planes[0].data_ptr(), rgbs[0].data_ptr(), full, stream.cuda_stream)
         e1.record(stream)
         torch.cuda.synchronize()
         resolve_ms = e0.elapsed_time(e1) / 10.0
@@ -218,7 +230,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_samples = w * h * s * s
-        mean_radiance = float(rgb.mean().item())
+        mean_radiance = float(rgbs[0].mean().item())
         out = {
             "metric": "Msamples/s (camera samples, each traced to its end: primary, scattered and shadow rays)",
             "value": round(total_samples / (elapsed / args.steps) / 1e6, 2),
@@ -240,7 +252,7 @@ def main():
                 "render_seed": 1,
                 "max_depth": 10,
                 "intersection": "uniform grid" if args.grid else "every sphere (LDS-resident or LDS-tiled)",
-                "frames_in_flight": 1 if (args.sync_reduce or world == 1) else 2,
+                "frames_in_flight": lanes,
             },
             "mrays_per_s": round(stats["ray_queries"] / (elapsed / args.steps) / 1e6, 1),
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),

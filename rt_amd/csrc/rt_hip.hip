@@ -628,8 +628,20 @@ struct Library
   char name[256] = {0};
   hipStream_t stream = nullptr;       // trace launches of the job API
   hipStream_t copy_stream = nullptr;  // snapshots, so they never queue behind a running trace
-  float * workspace = nullptr;        // column sums of rt_hip_trace_device calls, grown on demand
-  size_t workspace_bytes = 0;
+  // What an rt_hip_trace_device call needs besides its arguments, one set per caller stream so that calls on
+  // different streams may overlap: column sums + sample-sharing room, the camera table, counters.  Grow-only.
+  struct Workspace
+  {
+    hipStream_t stream = nullptr;
+    bool used = false;
+    float * partial = nullptr;
+    size_t partial_bytes = 0;
+    f4 * camtab = nullptr;
+    size_t camtab_entries = 0;
+    unsigned long long * stats = nullptr;  // kStatsWords + 1 words, for callers that pass no d_stats
+  };
+  static constexpr int kWorkspaces = 8;
+  Workspace workspaces[kWorkspaces];
   uint32_t * never_cancel = nullptr;  // a zero word for traces that cannot be cancelled
   float * jitter_tab = nullptr;       // RT_JITTER_FLOATS, see rt_core.h jitter_ball
   rt_hip_job * spare_job = nullptr;   // buffers of the last finished job, see free_job
@@ -838,14 +850,17 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
 // kernel.  The camera table lives in the scene, so one scene carries one trace at a time.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
                  float * d_partial, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, size_t capacity, const uint32_t * d_cancel = nullptr)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, size_t capacity, const uint32_t * d_cancel = nullptr,
+                 f4 * d_camtab = nullptr)
 {
+  if (d_camtab == nullptr)
+    d_camtab = scene->d_camtab;  // one trace at a time per scene then
   TraceArgs a;
   std::memset(&a, 0, sizeof(a));
   prepare_frame(*camera, *p, a);
   a.spheres = scene->d_spheres;
   a.filter = scene->d_filter;
-  a.camtab = scene->d_camtab;
+  a.camtab = d_camtab;
   a.sphere_mat = scene->d_sphere_mat;
   a.materials = scene->d_materials;
   a.lights = scene->d_lights;
@@ -881,7 +896,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   if (scene->n_padded > 0)
   {
     int const tab_blocks = (int)((scene->n_padded + 255u) / 256u);
-    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, scene->d_camtab,
+    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, d_camtab,
                        scene->n_padded, a.cam_pos, a.col_delta);
     RT_CHECK(hipGetLastError());
   }
@@ -1093,9 +1108,13 @@ void rt_hip_shutdown(void)
   (void)hipStreamDestroy(g_lib.copy_stream);
   destroy_job(g_lib.spare_job);
   g_lib.spare_job = nullptr;
-  if (g_lib.workspace) (void)hipFree(g_lib.workspace);
-  g_lib.workspace = nullptr;
-  g_lib.workspace_bytes = 0;
+  for (Library::Workspace & w : g_lib.workspaces)
+  {
+    if (w.partial) (void)hipFree(w.partial);
+    if (w.camtab) (void)hipFree(w.camtab);
+    if (w.stats) (void)hipFree(w.stats);
+    w = Library::Workspace();
+  }
   g_lib.stream = nullptr;
   g_lib.copy_stream = nullptr;
   g_lib.ready = false;
@@ -1354,34 +1373,61 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
     return rc;
   if (d_sum_planes == nullptr)
     return fail(RT_HIP_ERR_INVALID, "null output");
-  // Without a caller buffer the counters (and the queue word behind them) live in a per-process scratch.
-  static unsigned long long * s_scratch = nullptr;
+  hipStream_t const hs = static_cast<hipStream_t>(stream);
+  // This stream's workspace: calls on one stream are ordered and share it, calls on different streams overlap.
+  Library::Workspace * ws = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_lib.mutex);
+    for (Library::Workspace & w : g_lib.workspaces)
+      if (w.used && w.stream == hs)
+        ws = &w;
+    for (Library::Workspace & w : g_lib.workspaces)
+      if (ws == nullptr && !w.used)
+      {
+        w.used = true;
+        w.stream = hs;
+        ws = &w;
+      }
+  }
+  if (ws == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_trace_device: more than 8 different streams");
+  size_t const need = trace_buffer_bytes(params);
+  if (ws->partial_bytes < need)
+  {
+    if (ws->partial != nullptr)
+    {
+      RT_CHECK(hipStreamSynchronize(hs));
+      (void)hipFree(ws->partial);
+      ws->partial = nullptr;
+      ws->partial_bytes = 0;
+    }
+    RT_CHECK(hipMalloc((void **)&ws->partial, need));
+    ws->partial_bytes = need;
+  }
+  if (ws->camtab_entries < std::max<size_t>(scene->n_padded, 1))
+  {
+    if (ws->camtab != nullptr)
+    {
+      RT_CHECK(hipStreamSynchronize(hs));
+      (void)hipFree(ws->camtab);
+      ws->camtab = nullptr;
+      ws->camtab_entries = 0;
+    }
+    RT_CHECK(hipMalloc((void **)&ws->camtab, sizeof(f4) * std::max<size_t>(scene->n_padded, 1)));
+    ws->camtab_entries = std::max<size_t>(scene->n_padded, 1);
+  }
+  // Without a caller buffer the counters (and the queue word behind them) live in the workspace.
   unsigned long long * st = static_cast<unsigned long long *>(d_stats);
   if (st == nullptr)
   {
-    if (s_scratch == nullptr)
-      RT_CHECK(hipMalloc((void **)&s_scratch, sizeof(unsigned long long) * (kStatsWords + 1)));
-    st = s_scratch;
+    if (ws->stats == nullptr)
+      RT_CHECK(hipMalloc((void **)&ws->stats, sizeof(unsigned long long) * (kStatsWords + 1)));
+    st = ws->stats;
   }
-  // Column sums go to a library workspace that only ever grows; the planes are accumulated from it.
-  size_t const need = trace_buffer_bytes(params);
-  if (g_lib.workspace_bytes < need)
-  {
-    if (g_lib.workspace != nullptr)
-    {
-      RT_CHECK(hipDeviceSynchronize());
-      (void)hipFree(g_lib.workspace);
-      g_lib.workspace = nullptr;
-      g_lib.workspace_bytes = 0;
-    }
-    RT_CHECK(hipMalloc((void **)&g_lib.workspace, need));
-    g_lib.workspace_bytes = need;
-  }
-  hipStream_t const hs = static_cast<hipStream_t>(stream);
-  int rc2 = launch_trace(scene, camera, params, g_lib.workspace, st, d_stats != nullptr, hs, nullptr, nullptr,
-                         g_lib.workspace_bytes);
+  int rc2 = launch_trace(scene, camera, params, ws->partial, st, d_stats != nullptr, hs, nullptr, nullptr,
+                         ws->partial_bytes, nullptr, ws->camtab);
   if (rc2 == RT_HIP_OK)
-    rc2 = launch_colsum(g_lib.workspace, d_sum_planes, params, hs);
+    rc2 = launch_colsum(ws->partial, d_sum_planes, params, hs);
   return rc2;
 }
 

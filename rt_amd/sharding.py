@@ -6,6 +6,8 @@ number (that index) % slice_count.  Every rank traces its slice into planar sums
 (RCCL over xGMI when the tensors live on GPUs, gloo on CPUs) rebuilds the frame's sums, which rank 0 then
 normalises.  The reference has no counterpart: its CUDA backend is single-GPU (rt_cuda/rt_cuda.cu:80).
 """
+import contextlib
+
 
 
 def owner_of(pixel, sx, sy, samples_in_row, slice_count):
@@ -42,10 +44,13 @@ class ReducePipeline:
     issued in frame order by every rank, as torch.distributed requires.
     """
 
-    def __init__(self, dist, world_size, buffers, on_done=None, root=0, rank=0):
+    def __init__(self, dist, world_size, buffers, on_done=None, root=0, rank=0, context=None):
         assert len(buffers) >= 2
         self.dist, self.world, self.buffers, self.on_done, self.root, self.rank = (
             dist, max(world_size, 1), buffers, on_done, root, rank)
+        # context(k): what frame k is retired under (on GPUs: the stream that owns the frame's buffer, so that
+        # the wait and on_done are ordered before the next use of that buffer); submit(k) is the caller's to wrap
+        self.context = context if context is not None else (lambda k: contextlib.nullcontext())
         self.pending = {}  # frame -> work handle (None when there was nothing to wait for)
 
     def acquire(self, k):
@@ -71,7 +76,8 @@ class ReducePipeline:
 
     def _retire(self, k):
         work = self.pending.pop(k)
-        if work is not None:
-            work.wait()  # on GPUs: makes the current stream wait for the collective
-        if self.on_done is not None and self.rank == self.root:
-            self.on_done(k, self.buffers[k % len(self.buffers)])
+        with self.context(k):
+            if work is not None:
+                work.wait()  # on GPUs: makes the current stream wait for the collective
+            if self.on_done is not None and self.rank == self.root:
+                self.on_done(k, self.buffers[k % len(self.buffers)])

@@ -19,21 +19,26 @@ if os.environ.get("RT_LIB_DIR"):
 r = ffi.HipRenderer(0)
 scene = ffi.Scene.demo(1, 1)
 w, h, s = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1920, 1080, 16)
-planes = torch.empty(3 * w * h, dtype=torch.float32, device="cuda")
-stats = torch.zeros(16, dtype=torch.int64, device="cuda")
-stream = torch.cuda.current_stream().cuda_stream
+planes = [torch.empty(3 * w * h, dtype=torch.float32, device="cuda") for _ in range(2)]
+stats = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(2)]
+# one stream, then two streams taking turns (different priorities, so that HIP gives them hardware queues of
+# their own): the second number is the period of a stream of frames whose ends and starts overlap
+streams = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)]
 base = None
 for g in ([int(v) for v in sys.argv[4].split(",")] if len(sys.argv) >= 5 else (1, 2, 4, 8)):
     p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1), 0, g)
-    for _ in range(2):
-        r.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 10
-    for _ in range(n):
-        r.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
+    ms = []
+    for lanes in (1, 2):
+        for k in range(4):
+            r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 12
+        for k in range(n):
+            r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) / n * 1e3)
     base = base or ms
-    print("G = %d: %.3f ms per frame slice; %.2fx of the whole frame's time; ideal %.3f ms" % (g, ms, base / ms, base / g))
+    print("G = %d: %.3f ms per frame slice (%.2fx of the whole frame's time; ideal %.3f ms); %.3f ms with two frames "
+          "in flight (%.2fx)" % (g, ms[0], base[0] / ms[0], base[0] / g, ms[1], base[1] / ms[1]))
 r.close()
