@@ -163,6 +163,33 @@ def test_device_path_slices_reduce_to_the_frame(hip, ffi, scenes, world):
     np.testing.assert_allclose(rgb.cpu().numpy().reshape(h, w, 3), ref, rtol=2e-6, atol=1e-7)
 
 
+def test_device_path_calls_on_two_streams_overlap_safely(hip, ffi, scenes):
+    """rt_hip_trace_device keeps a workspace per stream: frames in flight on two streams at once (different seeds
+    and scenes, several rounds) come out exactly as when traced one at a time."""
+    import torch
+
+    w, h, s = 640, 360, 4
+    jobs = [(scenes(1), ffi.params(w, h, s, seed=3)), (scenes(2), ffi.params(w, h, s, seed=8))]
+    alone = []
+    stats = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in jobs]
+    planes = [torch.empty(3 * w * h, dtype=torch.float32, device="cuda") for _ in jobs]
+    default = torch.cuda.current_stream().cuda_stream
+    for i, (scene, p) in enumerate(jobs):
+        hip.trace_device(scene, p, planes[i].data_ptr(), stats[i].data_ptr(), default)
+        torch.cuda.synchronize()
+        alone.append((planes[i].clone(), stats[i][:6].clone()))
+    streams = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)]
+    for _ in range(3):
+        for i, (scene, p) in enumerate(jobs):
+            planes[i].fill_(float("nan"))
+            streams[i].wait_stream(torch.cuda.current_stream())
+            hip.trace_device(scene, p, planes[i].data_ptr(), stats[i].data_ptr(), streams[i].cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(jobs)):
+            assert torch.equal(planes[i], alone[i][0])
+            assert torch.equal(stats[i][:6], alone[i][1])
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     """bench.py on a small frame: one JSON line on stdout with the fields the driver reads."""
     import sys
