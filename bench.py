@@ -258,7 +258,8 @@ def main():
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),
             "mean_radiance": round(mean_radiance, 5),
             "roofline": {
-                "bound": "valu_fp32",
+                "bound": "valu_fp32" if not args.grid else "latency (grid walk; achieved/frac below still credit "
+                                                          "the brute-force test count and do not apply)",
                 "bound_note": "FP32 vector-ALU issue; this kernel is neither HBM- nor MFMA-bound "
                               "(0.43 GB of HBM traffic per 3.2 TFLOP launch, no matrix work)",
                 "achieved": round(achieved, 2),
