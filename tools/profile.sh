@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- \
-  python3 "$ROOT/bench.py" --steps 5 --warmup 2 > "$OUT/bench_stdout.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/bench_stdout.log"; exit 1; }
+  python3 "$ROOT/bench.py" --steps 5 --warmup 2 --sync-reduce > "$OUT/bench_stdout.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/bench_stdout.log"; exit 1; }
 
 ONE="python3 $ROOT/tools/render_once.py 1 1920 1080 16"
 pass() {
