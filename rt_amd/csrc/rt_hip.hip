@@ -44,6 +44,10 @@ constexpr int kWavesPerSimd = 3;          // blocks per CU the register budget i
 // free slots, one per shader engine of the 8 XCDs, a snapshot runs beside the trace; with 16 it waits.)
 constexpr int kWavesPerSimdForward = 4;
 constexpr int kSnapshotReserveBlocks = 64;
+// ... but only for frames long enough for anyone to look at them while they render (the reference's viewer
+// asks every 0.25 s, app.cpp:64-71): below this many samples (about 0.1 s of tracing) a job takes the whole chip
+// and a snapshot waits for the frame's end.
+constexpr unsigned long long kSnapshotRoomSamples = 1500000000ull;
 constexpr uint32_t kResidentMaterials = 256;  // resident scenes also keep their materials and lights in LDS
 constexpr uint32_t kResidentLights = 16;
 constexpr uint32_t kColumnMaskSpheres = 64;   // column masks: two 32-bit words per lane
@@ -900,7 +904,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
                        scene->n_padded, a.cam_pos, a.col_delta);
     RT_CHECK(hipGetLastError());
   }
-  int const blocks = persistent_blocks(scene, p->flags, a.n_items, d_cancel != nullptr);
+  bool const leave_room = d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples;
+  int const blocks = persistent_blocks(scene, p->flags, a.n_items, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   size_t const lds = lds_bytes(scene, p->flags);
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.

@@ -21,7 +21,7 @@ def test_device_is_an_mi355x(hip):
 
 def test_job_runs_asynchronously_and_snapshots_progress(hip, ffi, scenes):
     scene = scenes(2)
-    p = ffi.params(1920, 1080, 16, seed=3)
+    p = ffi.params(3840, 2160, 16, seed=3)  # long enough (0.14 s) for the job to keep room for snapshots
     t0 = time.perf_counter()
     job = hip.start(scene, p)
     launch = time.perf_counter() - t0
@@ -33,7 +33,7 @@ def test_job_runs_asynchronously_and_snapshots_progress(hip, ffi, scenes):
     # a snapshot holds finished columns only: every pixel is at most its final value, unfinished ones darker
     assert (snap <= final * (1 + 1e-5) + 1e-6).all()
     assert still_running and (snap.sum(axis=2) < final.sum(axis=2) * 0.999).any()
-    assert st.samples == 1920 * 1080 * 256 and st.kernel_ms > 0
+    assert st.samples == 3840 * 2160 * 256 and st.kernel_ms > 0
 
 
 def test_cancel_stops_the_frame_early(hip, ffi, scenes):
