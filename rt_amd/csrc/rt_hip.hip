@@ -1,15 +1,19 @@
 // rt_hip.hip -- gfx950 kernels and the C ABI of the MI355X ray-tracing backend (include/rt_hip.h).
 //
 // Kernels
-//   trace_kernel<false, *>  persistent waves; the whole scene (<= kResidentSpheres spheres) sits in LDS for
+//   trace_kernel<false, *, *>  persistent waves; the whole scene (<= kResidentSpheres spheres) sits in LDS for
 //                        the life of the block; every lane runs the path state machine of rt_core.h and
-//                        takes sub-sample columns from one frame-wide atomic counter, a batch of 64 per
-//                        atomic.  Waves never wait for each other.
-//   trace_kernel<true, *>   the same loop for larger scenes: the block re-stages the spheres through LDS in
+//                        takes sub-sample columns from one frame-wide atomic counter, a reservation of 64 or
+//                        more per atomic, fewer towards the end.  Waves never wait for each other.
+//   trace_kernel<true, *, *>   the same loop for larger scenes: the block re-stages the spheres through LDS in
 //                        tiles of kTileSpheres inside every ray pass, so its waves stay in step.
-//   trace_kernel<*, true>   paths accumulated forward in registers; <*, false> keeps the reference's reverse
-//                        loop over a 10-entry stack per lane in LDS (40 KB per block).
-//   colsum_kernel        accumulate pass: per pixel, the column sums of the slice -> planar pixel sums.
+//   trace_kernel<*, true, *>   paths accumulated forward in registers; <*, false, *> keeps the reference's
+//                        reverse loop over a 10-entry stack per lane in LDS (40 KB per block).
+//   trace_kernel<*, *, true>   scenes with one light: no shading state carried from trip to trip.
+//   trace_kernel_grid    the same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).
+//   fold_kernel          completes the sums of columns whose last samples were traced by other lanes of the
+//                        owner's wave (sample sharing at the end of the queue).
+//   colsum_kernel        accumulate pass: per pixel, its column sums -> planar pixel sums.
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
 //                        16 bytes per lane per access.  These two are the HBM-bound passes.
 //
