@@ -17,7 +17,7 @@
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
 //                        16 bytes per lane per access.  These two are the HBM-bound passes.
 //
-//   camtab_kernel        per-frame table of the primary-ray filter, one entry per sphere.
+//   camtab_kernel        per-launch set-up: table of the primary-ray filter (one entry per sphere), counters reset.
 //
 // LDS per block: the resident scene (48 B per sphere and material, 32 B per light) and 8 KB of prepared
 // columns, or one 16 KB staging tile for scenes above kResidentSpheres spheres.
@@ -507,11 +507,19 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
   flush_counters(A, cnt);
 }
 
-// The primary-ray filter table: per (padded) sphere, (centre - camera, filter bound).  One thread per entry.
+// Per-launch set-up in one small kernel: the primary-ray filter table -- per sphere, (centre - camera, filter
+// bound) -- and the words a trace starts from zero (its counters and queue word, the split-record count).
+// One thread per table entry, at least one block.
 __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ filter, f4 * __restrict__ camtab,
-                                                     uint32_t n_padded, f3 cam_pos, float col_delta)
+                                                     uint32_t n_padded, f3 cam_pos, float col_delta,
+                                                     unsigned long long * __restrict__ stats, uint32_t stats_words,
+                                                     uint32_t * __restrict__ split_count)
 {
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < stats_words)
+    stats[i] = 0ull;
+  if (i == 0u && split_count != nullptr)
+    *split_count = 0u;
   if (i >= n_padded)
     return;
   f4 const s = filter[i];
@@ -850,7 +858,7 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
   return RT_HIP_OK;
 }
 
-// Enqueues, on `stream`: counter reset, the camera table for this frame's camera, the trace kernel and, with
+// Enqueues, on `stream`: the set-up kernel (camera table for this frame's camera, counters reset), the trace kernel and, with
 // sample sharing, the fold pass.  d_partial receives the column sums of this slice; `capacity` is the size of
 // the buffer behind it: sample sharing is on when it has room for the records and colours behind the column
 // sums (trace_buffer_bytes). d_stats points at kStatsWords counters followed by the
@@ -886,7 +894,6 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.batch_items = batch_items(p, g_lib.compute_units);
   a.batch_min = batch_min(p, a.batch_items);
 
-  RT_CHECK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (kStatsWords + 1), stream));
   if (uses_grid(scene, p->flags))
   {
     a.grid_start = scene->d_grid_start;
@@ -901,13 +908,6 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   a.column_masks = (uses_column_masks(scene) && !uses_grid(scene, p->flags)) ? 1u : 0u;
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
-  if (scene->n_padded > 0)
-  {
-    int const tab_blocks = (int)((scene->n_padded + 255u) / 256u);
-    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, d_camtab,
-                       scene->n_padded, a.cam_pos, a.col_delta);
-    RT_CHECK(hipGetLastError());
-  }
   bool const leave_room = d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples;
   int const blocks = persistent_blocks(scene, p->flags, a.n_items, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
@@ -922,7 +922,12 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     a.splits = reinterpret_cast<u4 *>(base + 16);
     a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
     a.share_depth = share_depth(p);
-    RT_CHECK(hipMemsetAsync(a.split_count, 0, 16, stream));
+  }
+  {
+    int const tab_blocks = std::max(1, (int)((scene->n_padded + 255u) / 256u));
+    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, d_camtab,
+                       scene->n_padded, a.cam_pos, a.col_delta, d_stats, (uint32_t)(kStatsWords + 1), a.split_count);
+    RT_CHECK(hipGetLastError());
   }
   if (ev_start)
     RT_CHECK(hipEventRecord(ev_start, stream));
