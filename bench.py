@@ -134,7 +134,7 @@ def main():
     renderer = ffi.HipRenderer(local_rank)  # raises if librt_hip.so or the GPU is missing: no fallback
     scene = ffi.Scene.demo(args.demo, 1, args.spheres)
     w, h, s = args.width, args.height, args.samples
-    flags = ffi.FLAG_GRID if args.grid else 0
+    flags = (ffi.FLAG_GRID if args.grid else 0) | (0 if args.sync_reduce else ffi.FLAG_PIPELINED)
     p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world)
     full = ffi.params(w, h, s, seed=1, flags=flags)
 

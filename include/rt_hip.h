@@ -47,6 +47,10 @@ extern "C" {
 #define RT_HIP_FLAG_GRID 2u          /* rays walk a uniform grid over the spheres instead of testing every sphere
                                         (scenes of 64 spheres or more; ignored for smaller ones).  Same image: the
                                         grid only selects which spheres the exact intersection is run on. */
+#define RT_HIP_FLAG_PIPELINED 4u     /* the frame is one of a stream of frames traced on alternating streams
+                                        (rt_hip_trace_device): the next frame's waves fill the compute units its
+                                        end leaves idle, so the launch keeps its work reservations large to the end
+                                        instead of shrinking them to finish early.  Same image. */
 
 /* Replaces CudaMaterial (rt_cuda/types_cuda.h): what Material::GetType/GetAlbedo/GetRoughness/
  * GetRefraction return (ray_tracing/material.hpp:20-26). */

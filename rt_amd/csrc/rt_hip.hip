@@ -892,7 +892,9 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
   a.batch_items = batch_items(p, g_lib.compute_units);
-  a.batch_min = batch_min(p, a.batch_items);
+  // A frame that overlaps with the next one on another stream keeps full reservations to the end: the next
+  // frame's waves fill what its end leaves idle, and the smaller reservations would only cost throughput.
+  a.batch_min = (p->flags & RT_HIP_FLAG_PIPELINED) ? a.batch_items : batch_min(p, a.batch_items);
 
   if (uses_grid(scene, p->flags))
   {

@@ -9,6 +9,7 @@ _LIB_DIR = os.path.join(_HERE, "lib")
 
 FLAG_DETERMINISTIC = 1
 FLAG_GRID = 2
+FLAG_PIPELINED = 4
 
 RT_HIP_OK = 0
 RT_HIP_ERR_NOT_READY = 3

@@ -26,9 +26,10 @@ stats = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(2)]
 streams = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)]
 base = None
 for g in ([int(v) for v in sys.argv[4].split(",")] if len(sys.argv) >= 5 else (1, 2, 4, 8)):
-    p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1), 0, g)
     ms = []
     for lanes in (1, 2):
+        flags = ffi.FLAG_PIPELINED if lanes == 2 else 0
+        p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), 0, g)
         for k in range(4):
             r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
         torch.cuda.synchronize()
