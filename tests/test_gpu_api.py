@@ -190,6 +190,21 @@ def test_device_path_calls_on_two_streams_overlap_safely(hip, ffi, scenes):
             assert torch.equal(stats[i][:6], alone[i][1])
 
 
+def test_reduce_pipeline_over_rccl_with_one_rank(tmp_path):
+    """The asynchronous reduces bench.py issues from two streams, over the nccl (= RCCL) backend: all a one-GPU box
+    can exercise of it is a group of one rank, which still goes through the collective calls."""
+    import socket
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_pipeline_check.py"), str(port)],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "pipeline ok" in res.stdout
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     """bench.py on a small frame: one JSON line on stdout with the fields the driver reads."""
     import sys
