@@ -209,8 +209,10 @@ def main():
     stats = dict(zip(names, (int(x) for x in counters.tolist())))
 
     # roofline of the dominant kernel: this rank's trace kernel, HIP events on its launch stream
+    # (launched alone, one after the other, so without the flag that tells a launch its successor overlaps it)
     launches = max(2, min(args.steps, 5))
-    kernel_ms, kstats = renderer.time_trace_kernel(scene, p, launches)
+    p_alone = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED), rank, world)
+    kernel_ms, kstats = renderer.time_trace_kernel(scene, p_alone, launches)
     k = kstats.as_dict()
     kernel_flop = algorithmic_flop(k, scene.sphere_count)
     achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
