@@ -198,6 +198,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The same frame one at a time (no overlap of frames, no flag that announces one): what a caller that needs
+    # each image before it asks for the next would see.  Reported beside the headline, never as it.
+    p_alone = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED), rank, world)
+    singles = max(2, min(args.steps, 5))
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(singles):
+        stream = torch.cuda.current_stream().cuda_stream
+        renderer.trace_device(scene, p_alone, planes[0].data_ptr(), d_stats[1].data_ptr(), stream)
+        if rehearsing:
+            host[0].copy_(planes[0])
+            sharding.reduce_to_root(dist, host[0], world)
+            planes[0].copy_(host[0])
+        else:
+            sharding.reduce_to_root(dist, planes[0], world)
+        if rank == 0:
+            renderer.resolve_device(planes[0].data_ptr(), rgbs[1].data_ptr(), full, stream)
+    fence()
+    single_ms = (time.perf_counter() - t1) / singles * 1e3
+    if distributed:
+        t = torch.tensor([single_ms], dtype=torch.float64, device="cpu" if args.rehearse else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        single_ms = float(t.item())
+
     # counters of this rank's last trace, summed over ranks
     counters = d_stats[0][:8].clone()
     if distributed:
@@ -211,7 +235,6 @@ def main():
     # roofline of the dominant kernel: this rank's trace kernel, HIP events on its launch stream
     # (launched alone, one after the other, so without the flag that tells a launch its successor overlaps it)
     launches = max(2, min(args.steps, 5))
-    p_alone = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED), rank, world)
     kernel_ms, kstats = renderer.time_trace_kernel(scene, p_alone, launches)
     k = kstats.as_dict()
     kernel_flop = algorithmic_flop(k, scene.sphere_count)
@@ -256,6 +279,7 @@ def main():
                 "intersection": "uniform grid" if args.grid else "every sphere (LDS-resident or LDS-tiled)",
                 "frames_in_flight": lanes,
             },
+            "ms_per_frame_one_at_a_time": round(single_ms, 3),
             "mrays_per_s": round(stats["ray_queries"] / (elapsed / args.steps) / 1e6, 1),
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),
             "mean_radiance": round(mean_radiance, 5),
