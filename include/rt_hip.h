@@ -165,9 +165,10 @@ int rt_hip_job_cancel(rt_hip_job * job);
  * overwritten) on `stream` (a hipStream_t passed as void*; NULL = the default stream), asynchronously.
  * d_stats (device memory, 128 bytes, may be NULL) receives the eight uint64 counters of rt_hip_stats for
  * this call, in declaration order (the kernel also keeps its queue word there, so calls in flight at the same
- * time need different buffers).  Calls on one stream run in order; calls on different streams (at most eight
- * streams per process) may overlap -- the library keeps a grow-only workspace per stream -- which lets the
- * start of one frame fill the compute units that the end of the previous frame leaves idle. */
+ * time need different buffers).  Calls on one stream run in order; calls on different streams may overlap --
+ * the library keeps a grow-only workspace per stream, eight of them (a ninth stream takes over the least
+ * recently used one after a device-wide wait) -- which lets the start of one frame fill the compute units
+ * that the end of the previous frame leaves idle. */
 int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera,
                         const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
                         void * stream);

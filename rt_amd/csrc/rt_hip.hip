@@ -655,7 +655,9 @@ struct Library
     f4 * camtab = nullptr;
     size_t camtab_entries = 0;
     unsigned long long * stats = nullptr;  // kStatsWords + 1 words, for callers that pass no d_stats
+    unsigned long long last_use = 0;       // for handing the least recently used set to a ninth stream
   };
+  unsigned long long workspace_clock = 0;
   static constexpr int kWorkspaces = 8;
   Workspace workspaces[kWorkspaces];
   uint32_t * never_cancel = nullptr;  // a zero word for traces that cannot be cancelled
@@ -1404,9 +1406,19 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
         w.stream = hs;
         ws = &w;
       }
+    if (ws == nullptr)
+    {
+      // every set belongs to some stream: the least recently used one changes hands once the device is idle
+      // (its old stream may no longer exist, so there is nothing narrower to wait for)
+      ws = &g_lib.workspaces[0];
+      for (Library::Workspace & w : g_lib.workspaces)
+        if (w.last_use < ws->last_use)
+          ws = &w;
+      RT_CHECK(hipDeviceSynchronize());
+      ws->stream = hs;
+    }
+    ws->last_use = ++g_lib.workspace_clock;
   }
-  if (ws == nullptr)
-    return fail(RT_HIP_ERR_INVALID, "rt_hip_trace_device: more than 8 different streams");
   size_t const need = trace_buffer_bytes(params);
   if (ws->partial_bytes < need)
   {

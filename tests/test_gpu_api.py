@@ -190,6 +190,24 @@ def test_device_path_calls_on_two_streams_overlap_safely(hip, ffi, scenes):
             assert torch.equal(stats[i][:6], alone[i][1])
 
 
+def test_device_path_serves_more_streams_than_it_has_workspaces(hip, ffi, scenes):
+    import torch
+
+    scene = scenes(1)
+    w, h, s = 96, 54, 3
+    p = ffi.params(w, h, s, seed=2)
+    planes = torch.empty(3 * w * h, dtype=torch.float32, device="cuda")
+    stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+    first = None
+    for _ in range(12):  # the library keeps eight sets of buffers
+        stream = torch.cuda.Stream()
+        hip.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        if first is None:
+            first = planes.clone()
+        assert torch.equal(planes, first)
+
+
 def test_reduce_pipeline_over_rccl_with_one_rank(tmp_path):
     """The asynchronous reduces bench.py issues from two streams, over the nccl (= RCCL) backend: all a one-GPU box
     can exercise of it is a group of one rank, which still goes through the collective calls."""
