@@ -1,0 +1,33 @@
+"""Condenses the kernel trace of tools/overlap_trace.sh into profiles/<tag>_overlap.txt: one line per trace-kernel
+launch of the timed region with its hardware queue, start and end.
+
+python tools/summarise_overlap.py <tag>
+"""
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", "overlap_" + tag)
+rows = [r for r in csv.DictReader(open(os.path.join(src, "ov_kernel_trace.csv"))) if "trace_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+with open(os.path.join(src, "stdout.log")) as f:
+    line = [l for l in f if l.startswith('{"metric"')][-1]
+out = os.path.join(ROOT, "profiles", tag + "_overlap.txt")
+with open(out, "w") as f:
+    f.write("rocprofv3 --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline (tools/overlap_trace.sh):\n"
+            "the trace_kernel launches in start order.  Frames alternate between two streams of different priority, which\n"
+            "HIP maps to two hardware queues; a frame's kernel starts while the previous frame's is still running, so the\n"
+            "period between starts is shorter than a kernel.  The last launches (one queue, back to back) are the\n"
+            "one-at-a-time frames and the roofline timing of the same run.\n\n")
+    f.write("queue  start ms   end ms     duration ms  start - previous start ms\n")
+    t0 = int(rows[0]["Start_Timestamp"])
+    prev = None
+    for r in rows:
+        s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+        f.write("%5s  %9.3f  %9.3f  %10.3f  %s\n" % (r.get("Queue_Id", "?"), s, e, e - s,
+                                                      "" if prev is None else "%9.3f" % (s - prev)))
+        prev = s
+    f.write("\nbench line of the same run:\n" + line)
+print(open(out).read())
