@@ -1,7 +1,7 @@
 """What one rank of G does per frame: the time of rt_hip_trace_device (trace + accumulate pass) on slice 0 of G
 of the headline frame, against 1/G of the whole frame.  Leaves out the RCCL reduce, which needs the other GPUs.
 
-python tools/slice_timing.py [width height samples_in_row [slice counts]]       (RT_LIB_DIR=dir picks another build of the libraries)
+python tools/slice_timing.py [width height samples_in_row [slice counts [demo [spheres]]]]       (RT_LIB_DIR=dir picks another build of the libraries)
 """
 import os
 import sys
@@ -17,7 +17,8 @@ if os.environ.get("RT_LIB_DIR"):
     ffi._LIB_DIR = os.path.abspath(os.environ["RT_LIB_DIR"])
 
 r = ffi.HipRenderer(0)
-scene = ffi.Scene.demo(1, 1)
+demo = int(sys.argv[5]) if len(sys.argv) >= 6 else 1
+scene = ffi.Scene.demo(demo, 1, int(sys.argv[6]) if len(sys.argv) >= 7 else 10000)
 w, h, s = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1920, 1080, 16)
 planes = [torch.empty(3 * w * h, dtype=torch.float32, device="cuda") for _ in range(2)]
 stats = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(2)]
@@ -30,11 +31,11 @@ for g in ([int(v) for v in sys.argv[4].split(",")] if len(sys.argv) >= 5 else (1
     for lanes in (1, 2):
         flags = ffi.FLAG_PIPELINED if lanes == 2 else 0
         p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), 0, g)
-        for k in range(4):
+        for k in range(4 if demo != 3 else 1):
             r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 12
+        n = 12 if demo != 3 else 2
         for k in range(n):
             r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
         torch.cuda.synchronize()
