@@ -243,3 +243,26 @@ def test_non_finite_spheres_are_refused(hip, ffi):
                                 dict(position=(0.0, 0.5, -3.0), direction=(0.0, -0.2, 1.0)))
         with pytest.raises(ffi.HipError, match="non-finite sphere"):
             hip.render(scene, ffi.params(16, 16, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s_row,slices", [(2, 8), (3, 2), (5, 5), (16, 8)])
+def test_slice_rule_on_an_empty_scene(hip, ffi, s_row, slices):
+    """No spheres: every sample is the background, so a slice's pixel counts the samples it owns
+    (rt_amd.sharding.owner_of is the documented rule)."""
+    from rt_amd import sharding
+
+    w, h = 70, 33
+    scene = ffi.Scene.build([], [(0, (0.5, 0.5, 0.5), 0.5, 0.0)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
+    bg = np.array([scene.camera.background[k] for k in range(3)], dtype=np.float64)
+    pix = np.arange(w * h)
+    for r in (0, slices - 1):
+        owned = np.zeros(w * h)
+        for sx in range(s_row):
+            for sy in range(s_row):
+                owned += (((pix * s_row + sx) * s_row + sy) % slices) == r
+        assert sharding.owner_of(5, 1, 0, s_row, slices) == ((5 * s_row + 1) * s_row) % slices
+        out, st = hip.render(scene, ffi.params(w, h, s_row, seed=1, slice_index=r, slice_count=slices))
+        expect = owned.reshape(h, w)[:, :, None] * bg[None, None, :] / (s_row * s_row)
+        np.testing.assert_allclose(out, expect, rtol=1e-5)
+        assert st.samples == int(owned.sum())

@@ -163,3 +163,31 @@ def test_scene_file_through_the_checkers_frame(oracle, ffi, scenes, tmp_path):
     close = np.abs(a - b).max(axis=2) <= 1e-5 * np.maximum(np.abs(b).max(axis=2), 1e-3)
     assert close.mean() > 0.99
     assert sa.samples == sb.samples
+
+
+@pytest.mark.parametrize("s_row,slices", [(2, 8), (3, 2), (4, 3), (5, 5), (16, 8)])
+def test_slice_rule_is_the_documented_one(oracle, ffi, s_row, slices):
+    """An empty scene returns the background for every sample, so a slice's pixel is background * (samples it owns)
+    / S^2: the oracle, the host build of the kernel loop and rt_amd.sharding.owner_of must agree on who owns what."""
+    import emu_ffi
+    from rt_amd import sharding
+
+    w, h = 7, 5
+    scene = ffi.Scene.build([], [(0, (0.5, 0.5, 0.5), 0.5, 0.0)], [], dict(position=(0, 0, -3), direction=(0, 0, 1)))
+    bg = np.array([scene.camera.background[k] for k in range(3)], dtype=np.float64)
+    assert bg.min() > 0
+    total = 0
+    for r in range(slices):
+        p = ffi.params(w, h, s_row, seed=1, slice_index=r, slice_count=slices)
+        owned = np.zeros((h, w))
+        for pixel in range(w * h):
+            owned[pixel // w, pixel % w] = sum(sharding.owner_of(pixel, sx, sy, s_row, slices) == r
+                                               for sx in range(s_row) for sy in range(s_row))
+        expect = owned[:, :, None] * bg[None, None, :] / (s_row * s_row)
+        ref, rs = oracle.render(scene, p, 2)
+        out, es = emu_ffi.render(scene, p)
+        np.testing.assert_allclose(ref, expect, rtol=1e-5)
+        np.testing.assert_allclose(out, expect, rtol=1e-5)
+        assert rs.samples == es["samples"] == int(owned.sum())
+        total += int(owned.sum())
+    assert total == w * h * s_row * s_row
