@@ -20,6 +20,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = ffi.HipRenderer(0)
 scenes = [ffi.Scene.demo(1, 1), ffi.Scene.demo(2, 1), ffi.Scene.demo(3, 1, 100), ffi.Scene.demo(3, 1, 700)]
 cases = worst = 0
+worst_case = ""
 t_end = time.time() + budget
 while time.time() < t_end:
     si = int(rng.integers(len(scenes)))
@@ -38,7 +39,8 @@ while time.time() < t_end:
                                                   slice_count=g), 8)
     out, st = r.render(scene, det)
     err = float((np.abs(ref - out) / np.maximum(np.abs(ref), 1e-3)).max())
-    worst = max(worst, err)
+    if err > worst:
+        worst, worst_case = err, "scene %d %dx%d s=%d slice %d/%d depth %d grid %d" % (si, w, h, s, idx, g, depth, grid)
     same = (st.samples, st.ray_queries, st.hit_queries, st.shaded_bounces) == (rs.samples, rs.ray_queries, rs.hit_queries,
                                                                               rs.shaded_bounces)
     sto = ffi.params(w, h, s, flags=grid, seed=seed, max_depth=depth, slice_index=idx, slice_count=g)
@@ -56,4 +58,4 @@ while time.time() < t_end:
         r.close()
         sys.exit(1)
 r.close()
-print("%d cases, worst deterministic error %.3g" % (cases, worst))
+print("%d cases, worst deterministic error %.3g (%s)" % (cases, worst, worst_case))
