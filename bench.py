@@ -19,7 +19,6 @@ duration measured by HIP events on its launch stream; `cpu_baseline` times the C
 reference's multithreaded path on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
