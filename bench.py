@@ -150,7 +150,10 @@ def main():
     lanes = 1 if args.sync_reduce else 2
     # (different priorities: HIP then gives the streams hardware queues of their own, without which the second
     # frame's kernels would simply queue behind the first's)
-    streams = [torch.cuda.Stream(device=device, priority=-(i % 2)) for i in range(lanes)]
+    try:
+        streams = [torch.cuda.Stream(device=device, priority=-(i % 2)) for i in range(lanes)]
+    except (RuntimeError, ValueError):  # no stream priorities here: still correct, the frames just take turns
+        streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
     planes = [torch.empty(3 * w * h, dtype=torch.float32, device=device) for _ in range(2)]
     rgbs = [torch.empty(w * h * 3, dtype=torch.float32, device=device) for _ in range(2)] if rank == 0 else None
     d_stats = [torch.zeros(16, dtype=torch.int64, device=device) for _ in range(2)]
