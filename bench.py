@@ -133,12 +133,6 @@ def main():
     renderer = ffi.HipRenderer(local_rank)  # raises if librt_hip.so or the GPU is missing: no fallback
     scene = ffi.Scene.demo(args.demo, 1, args.spheres)
     w, h, s = args.width, args.height, args.samples
-    # Two frames in flight pay off when waves run on their own (scene resident in LDS, or grid walks); the
-    # LDS-tiled kernel for larger scenes keeps the waves of a block in step, and two such launches on one chip only
-    # get in each other's way (measured: 10 000 spheres, 1/8 slice, 219 ms alone against 239 ms overlapped).
-    tiled = scene.sphere_count > 256 and not args.grid
-    if tiled:
-        args.sync_reduce = True
     flags = (ffi.FLAG_GRID if args.grid else 0) | (0 if args.sync_reduce else ffi.FLAG_PIPELINED)
     p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world)
     full = ffi.params(w, h, s, seed=1, flags=flags)

@@ -789,13 +789,16 @@ int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long lon
 // Items per queue reservation: about 1024 samples' worth (16 columns of 64 ... one column of 1024 samples),
 // but few enough that every wave of a full grid still makes several reservations (load balance at the end of
 // the frame), and always a multiple of the window.
-uint32_t batch_items(const rt_hip_trace_params * p, int compute_units)
+// (`cost` scales the sample counts down for scenes whose samples cost more: the tiled path tests every sphere,
+// so a sample against 10 000 spheres takes forty times what one against 256 does, and a reservation sized in
+// samples alone would keep a wave busy for tens of milliseconds after the queue has run dry.)
+uint32_t batch_items(const rt_hip_trace_params * p, int compute_units, unsigned long long cost)
 {
   unsigned long long const g = p->slice_count ? p->slice_count : 1u;
   unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
   unsigned long long const per_column = std::max<unsigned long long>(1u, p->samples_in_row / g);  // of this slice
   unsigned long long const waves = (unsigned long long)std::max(compute_units, 1) * 4u * kWavesPerSimd;
-  unsigned long long k = (1024u + kItemBatch * per_column - 1u) / (kItemBatch * per_column);
+  unsigned long long k = (1024u / cost + kItemBatch * per_column - 1u) / (kItemBatch * per_column);
   unsigned long long const balance = items / (waves * kItemBatch * 4u);
   k = std::max<unsigned long long>(1u, std::min(k, balance));
   return (uint32_t)(k * kItemBatch);
@@ -803,11 +806,11 @@ uint32_t batch_items(const rt_hip_trace_params * p, int compute_units)
 
 // Smallest reservation near the end of the queue: about 256 samples' worth (the counter word stays well below
 // its limit even if every reservation were that small), at least one window.
-uint32_t batch_min(const rt_hip_trace_params * p, uint32_t batch)
+uint32_t batch_min(const rt_hip_trace_params * p, uint32_t batch, unsigned long long cost)
 {
   unsigned long long const g = p->slice_count ? p->slice_count : 1u;
   unsigned long long const per_column = std::max<unsigned long long>(1u, p->samples_in_row / g);
-  unsigned long long const k = (256u + kItemBatch * per_column - 1u) / (kItemBatch * per_column);
+  unsigned long long const k = std::max<unsigned long long>(1u, (256u / cost + kItemBatch * per_column - 1u) / (kItemBatch * per_column));
   return (uint32_t)std::min<unsigned long long>(k * kItemBatch, batch);
 }
 
@@ -893,10 +896,12 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
-  a.batch_items = batch_items(p, g_lib.compute_units);
+  unsigned long long const cost =
+      (is_tiled(scene) && !uses_grid(scene, p->flags)) ? std::max<unsigned long long>(1u, scene->n_spheres / kResidentSpheres) : 1u;
+  a.batch_items = batch_items(p, g_lib.compute_units, cost);
   // A frame that overlaps with the next one on another stream keeps full reservations to the end: the next
   // frame's waves fill what its end leaves idle, and the smaller reservations would only cost throughput.
-  a.batch_min = (p->flags & RT_HIP_FLAG_PIPELINED) ? a.batch_items : batch_min(p, a.batch_items);
+  a.batch_min = (p->flags & RT_HIP_FLAG_PIPELINED) ? a.batch_items : batch_min(p, a.batch_items, cost);
 
   if (uses_grid(scene, p->flags))
   {
