@@ -133,6 +133,12 @@ def main():
     renderer = ffi.HipRenderer(local_rank)  # raises if librt_hip.so or the GPU is missing: no fallback
     scene = ffi.Scene.demo(args.demo, 1, args.spheres)
     w, h, s = args.width, args.height, args.samples
+    # Two frames in flight pay off where the end of a launch is short against the launch (the small scenes of the
+    # reference's demos, or grid walks).  With hundreds of spheres tested per ray the last samples of a frame take
+    # long, the next frame's waves (on the higher-priority stream) crowd them out, and the frames end up slower
+    # than one at a time (measured: 251 spheres 43.6 ms alone, 50.6 ms overlapped): those run one at a time.
+    if scene.sphere_count > 64 and not args.grid:
+        args.sync_reduce = True
     flags = (ffi.FLAG_GRID if args.grid else 0) | (0 if args.sync_reduce else ffi.FLAG_PIPELINED)
     p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world)
     full = ffi.params(w, h, s, seed=1, flags=flags)

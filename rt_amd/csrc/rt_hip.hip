@@ -789,9 +789,10 @@ int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long lon
 // Items per queue reservation: about 1024 samples' worth (16 columns of 64 ... one column of 1024 samples),
 // but few enough that every wave of a full grid still makes several reservations (load balance at the end of
 // the frame), and always a multiple of the window.
-// (`cost` scales the sample counts down for scenes whose samples cost more: the tiled path tests every sphere,
-// so a sample against 10 000 spheres takes forty times what one against 256 does, and a reservation sized in
-// samples alone would keep a wave busy for tens of milliseconds after the queue has run dry.)
+// (`cost` scales the sample counts down for scenes whose samples cost more: without the grid every ray is tested
+// against every sphere, so a sample against 10 000 spheres takes a hundred and fifty times what one against the
+// 64 spheres these sizes were tuned on does, and a reservation sized in samples alone would keep a wave busy for
+// tens of milliseconds after the queue has run dry.)
 uint32_t batch_items(const rt_hip_trace_params * p, int compute_units, unsigned long long cost)
 {
   unsigned long long const g = p->slice_count ? p->slice_count : 1u;
@@ -896,8 +897,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
-  unsigned long long const cost =
-      (is_tiled(scene) && !uses_grid(scene, p->flags)) ? std::max<unsigned long long>(1u, scene->n_spheres / kResidentSpheres) : 1u;
+  unsigned long long const cost = uses_grid(scene, p->flags) ? 1u : std::max<unsigned long long>(1u, scene->n_spheres / 64u);
   a.batch_items = batch_items(p, g_lib.compute_units, cost);
   // A frame that overlaps with the next one on another stream keeps full reservations to the end: the next
   // frame's waves fill what its end leaves idle, and the smaller reservations would only cost throughput.
