@@ -19,6 +19,17 @@
  *     slice_count < 65536), so every slice takes every slice_count-th sample of each column.  The sums
  *     of all slices add up to the whole frame, which is how one frame is sharded over several GPUs
  *     (one process per GPU; the caller reduces the planes).
+ *
+ * Threads
+ *   - The library serves one device per process (the one rt_hip_init selected).  rt_hip_init for another device
+ *     releases what the library owns on the old one first; scenes and jobs made on the old device must have been
+ *     destroyed / finished by then.
+ *   - Scenes are immutable after rt_hip_scene_create and may be traced from several threads and in several jobs at
+ *     once (every job and every stream workspace has its own camera table).
+ *   - A job belongs to one thread at a time: poll / snapshot / cancel / finish of one job must not overlap.
+ *     Different jobs may be started and finished from different threads; they run on the library's trace stream
+ *     in the order they were started.
+ *   - rt_hip_trace_device may be called from several threads (one caller stream each).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -152,7 +163,9 @@ int rt_hip_job_poll(rt_hip_job * job);
 int rt_hip_job_snapshot(rt_hip_job * job, float * rgb);
 
 /* Replaces ray_tracing_cuda::FinishRayTrace (rt_cuda/rt_cuda.h:32): waits for the frame, writes the final
- * image to rgb (may be NULL), fills stats (may be NULL) and destroys the job. */
+ * image to rgb (may be NULL), fills stats (may be NULL) and destroys the job.  The image is already resolved on
+ * the device when the frame completes; the download runs on a copy stream of its own, so with a second job
+ * started before this call it overlaps that job's trace (fastest into pinned host memory). */
 int rt_hip_job_finish(rt_hip_job * job, float * rgb, rt_hip_stats * stats);
 
 /* Replaces the needInterrupt flag returned by the reference's realtimeHandler

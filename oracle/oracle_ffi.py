@@ -63,6 +63,9 @@ def load():
         lib.orc_render.restype = C.c_int
         lib.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32,
                                    C.c_void_p, C.POINTER(OrcStats)]
+        lib.orc_render_rows.restype = C.c_int
+        lib.orc_render_rows.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32,
+                                        C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
         lib.orc_philox4x32_10.restype = None
         lib.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32 * 2), C.POINTER(C.c_uint32 * 4)]
         lib.orc_uniform.restype = C.c_float
@@ -130,6 +133,21 @@ def render(scene, p, threads=None):
     if rc != 0:
         raise RuntimeError("orc_render failed with %d" % rc)
     return rgb, stats
+
+
+def render_rows(scene, p, row_begin, row_end, threads=None):
+    """Rows [row_begin, row_end) of the frame on the CPU; returns (rgb[row_end - row_begin, w, 3] float32, OrcStats)."""
+    lib = load()
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 16)
+    rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    stats = OrcStats()
+    s = orc_scene(scene)
+    rc = lib.orc_render_rows(C.byref(s), C.byref(scene.camera), C.byref(p), threads, row_begin, row_end,
+                             rgb.ctypes.data, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("orc_render_rows failed with %d" % rc)
+    return rgb[row_begin:row_end].copy(), stats
 
 
 _FRAME_PATH = os.path.join(_HERE, "liboracle_frame.so")

@@ -605,6 +605,7 @@ typedef struct
   const orc_params * params;
   float * rgb;
   uint32_t start_row, pitch;
+  uint32_t row_end; /* one past the last row of the band being rendered */
   orc_stats stats;
 } worker_ctx;
 
@@ -618,8 +619,9 @@ static void * worker(void * arg)
   float const inv_sample_count = 1.0f / (float)(s_row * s_row); /* frame.cpp:43 */
   memset(&w->stats, 0, sizeof(w->stats));
 
-  /* Thread i takes rows i, i + T, ... (multithreaded_frame.cpp:49 -> frame.cpp:44). */
-  for (uint32_t y = w->start_row; y < height; y += w->pitch)
+  /* Thread i takes rows i, i + T, ... (multithreaded_frame.cpp:49 -> frame.cpp:44), of the band. */
+  (void)height;
+  for (uint32_t y = w->start_row; y < w->row_end; y += w->pitch)
   {
     for (uint32_t x = 0; x < width; ++x)
     {
@@ -645,16 +647,16 @@ static void * worker(void * arg)
   return NULL;
 }
 
-int orc_render(const orc_scene * scene, const orc_camera * cam, const orc_params * params, uint32_t threads,
-               float * rgb, orc_stats * stats)
+int orc_render_rows(const orc_scene * scene, const orc_camera * cam, const orc_params * params, uint32_t threads,
+                    uint32_t row_begin, uint32_t row_end, float * rgb, orc_stats * stats)
 {
   if (!scene || !cam || !params || !rgb || params->width == 0 || params->height == 0 ||
-      params->samples_in_row == 0)
+      params->samples_in_row == 0 || row_begin >= row_end || row_end > params->height)
     return 1;
   if (threads == 0)
     threads = 1;
-  if (threads > params->height)
-    threads = params->height;
+  if (threads > row_end - row_begin)
+    threads = row_end - row_begin;
 
   worker_ctx * ctx = (worker_ctx *)calloc(threads, sizeof(worker_ctx));
   pthread_t * tid = (pthread_t *)calloc(threads, sizeof(pthread_t));
@@ -670,7 +672,8 @@ int orc_render(const orc_scene * scene, const orc_camera * cam, const orc_params
     ctx[i].cam = cam;
     ctx[i].params = params;
     ctx[i].rgb = rgb;
-    ctx[i].start_row = i;
+    ctx[i].start_row = row_begin + i;
+    ctx[i].row_end = row_end;
     ctx[i].pitch = threads;
   }
   int rc = 0;
@@ -702,4 +705,12 @@ int orc_render(const orc_scene * scene, const orc_camera * cam, const orc_params
   free(ctx);
   free(tid);
   return rc;
+}
+
+int orc_render(const orc_scene * scene, const orc_camera * cam, const orc_params * params, uint32_t threads,
+               float * rgb, orc_stats * stats)
+{
+  if (!params)
+    return 1;
+  return orc_render_rows(scene, cam, params, threads, 0u, params->height, rgb, stats);
 }

@@ -166,6 +166,11 @@ void orc_ray_trace(const orc_scene * scene, const orc_camera * cam, const orc_pa
 int orc_render(const orc_scene * scene, const orc_camera * cam, const orc_params * params, uint32_t threads,
                float * rgb, orc_stats * stats);
 
+/* The same for the rows [row_begin, row_end) of the frame only (the range of the row loop, ray_tracing/frame.cpp:44):
+ * rgb is still the whole frame, of which only those rows are written; stats count those rows. */
+int orc_render_rows(const orc_scene * scene, const orc_camera * cam, const orc_params * params, uint32_t threads,
+                    uint32_t row_begin, uint32_t row_end, float * rgb, orc_stats * stats);
+
 #ifdef __cplusplus
 }
 #endif

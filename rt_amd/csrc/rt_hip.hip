@@ -613,16 +613,15 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float * __restrict__
 
 // ---------------------------------------------------------------- host side
 
-thread_local std::string g_error;
+// The message of the last failing call on this thread, in a fixed buffer: reporting an error allocates nothing.
+thread_local char g_error[512] = {0};
 
 int fail(int code, const char * what, hipError_t e = hipSuccess)
 {
-  g_error = what;
   if (e != hipSuccess)
-  {
-    g_error += ": ";
-    g_error += hipGetErrorString(e);
-  }
+    std::snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(e));
+  else
+    std::snprintf(g_error, sizeof(g_error), "%s", what);
   return code;
 }
 
@@ -641,6 +640,7 @@ struct Library
   int device = 0;
   int compute_units = 0;
   int clock_khz = 0;
+  size_t lds_per_block = 65536;  // what one block may ask for without opting in to more
   char name[256] = {0};
   hipStream_t stream = nullptr;       // trace launches of the job API
   hipStream_t copy_stream = nullptr;  // snapshots, so they never queue behind a running trace
@@ -672,12 +672,20 @@ struct rt_hip_scene
 {
   f4 * d_spheres = nullptr;  // exact records, n_padded
   f4 * d_filter = nullptr;   // filter records, n_padded
-  f4 * d_camtab = nullptr;   // n_padded, rewritten by every trace for its camera
   uint32_t * d_sphere_mat = nullptr;
   f4 * d_materials = nullptr;
   f4 * d_lights = nullptr;
   uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
   bool forward_ok = false;  // paths can be accumulated forward (rt_prep.h forward_accumulation_ok)
+  // Blocks per compute unit of the trace kernel this scene is traced with, asked of the runtime once per kernel
+  // variant ([1]: the grid walk) and LDS size rather than on every launch.
+  struct Occupancy
+  {
+    size_t lds = ~(size_t)0;
+    bool tiled = false;
+    int per_cu = 0;
+  };
+  mutable Occupancy occupancy[2];
   // uniform grid for RT_HIP_FLAG_GRID traces (scenes of at least kGridMinSpheres spheres)
   bool has_grid = false;
   uint32_t * d_grid_start = nullptr;
@@ -696,9 +704,17 @@ struct rt_hip_job
   size_t pixels = 0;        // pixels behind d_planes / d_rgb
   float * d_partial = nullptr;  // the slice's column sums, RGB interleaved, then sample-sharing room (trace_buffer_bytes)
   float * d_planes = nullptr;
-  float * d_rgb = nullptr;
+  float * d_rgb = nullptr;  // the finished image: the accumulate and resolve passes follow the trace on its stream
+  f4 * d_camtab = nullptr;  // this frame's camera table
+  size_t camtab_entries = 0;
   unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
-  hipEvent_t start = nullptr, stop = nullptr;
+  hipEvent_t start = nullptr, stop = nullptr;  // directly around the trace kernel
+  hipEvent_t done = nullptr;                   // after the resolve pass: d_rgb is complete
+  // Snapshots of the running frame have an image of their own (the passes that produce d_rgb may run at the same
+  // time) and a pinned staging buffer for the download; all three are made by the first snapshot.
+  float * d_snap_planes = nullptr;
+  float * d_snap_rgb = nullptr;
+  float * h_snap = nullptr;
   uint32_t * h_cancel = nullptr;  // pinned host word the kernel polls; written by rt_hip_job_cancel
   bool cancelled = false;
 };
@@ -722,10 +738,21 @@ bool share_disabled() { return std::getenv("RT_HIP_NO_SHARING") != nullptr; }
 
 bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }
 
+// LDS of the resident layout: path stacks (scenes whose paths cannot be accumulated forward), the jitter table,
+// three records per sphere, the materials and lights, one prepared-column table per wave.
+size_t resident_lds_bytes(const rt_hip_scene * sc)
+{
+  return (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS +
+         sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + 2u * sc->n_lights) +
+         sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
+}
+
+// A scene is staged through LDS in tiles when it is too large to live there whole: too many records for the
+// resident layout's limits, or (with the path stacks of a scene that needs them) more bytes than a block may have.
 bool is_tiled(const rt_hip_scene * sc)
 {
   return sc->n_padded > kResidentSpheres || sc->n_materials > kResidentMaterials || sc->n_lights > kResidentLights ||
-         forced_tile() != 0u;
+         resident_lds_bytes(sc) > g_lib.lds_per_block || forced_tile() != 0u;
 }
 uint32_t tile_size() { return forced_tile() ? forced_tile() : kTileSpheres; }
 bool uses_column_masks(const rt_hip_scene * sc)
@@ -743,8 +770,7 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
   if (is_tiled(sc))
     bytes += sizeof(f4) * (size_t)kTileSpheres;
   else
-    bytes += sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + 2u * sc->n_lights) +
-             sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
+    bytes = resident_lds_bytes(sc);
   return std::max<size_t>(bytes, 16u);
 }
 
@@ -771,13 +797,19 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
 // more lanes than work items.
 int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long long items, bool leave_room)
 {
-  int per_cu = 0;
   size_t const lds = lds_bytes(sc, flags);
-  hipError_t const e = with_trace_kernel(sc, flags, [&](auto kernel) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds);
-  });
-  if (e != hipSuccess || per_cu < 1)
-    per_cu = 1;
+  rt_hip_scene::Occupancy & cached = sc->occupancy[uses_grid(sc, flags) ? 1 : 0];
+  if (cached.lds != lds || cached.tiled != is_tiled(sc) || cached.per_cu < 1)
+  {
+    int asked = 0;
+    hipError_t const e = with_trace_kernel(sc, flags, [&](auto kernel) {
+      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked, kernel, kBlock, lds);
+    });
+    cached.lds = lds;
+    cached.tiled = is_tiled(sc);
+    cached.per_cu = (e != hipSuccess || asked < 1) ? 1 : asked;
+  }
+  int const per_cu = cached.per_cu;
   long long blocks = (long long)per_cu * std::max(g_lib.compute_units, 1);
   if (leave_room && per_cu >= kWavesPerSimdForward)
     blocks -= kSnapshotReserveBlocks;
@@ -869,14 +901,12 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
 // the buffer behind it: sample sharing is on when it has room for the records and colours behind the column
 // sums (trace_buffer_bytes). d_stats points at kStatsWords counters followed by the
 // queue counter (one 8-byte slot).  When events are given they are recorded directly around the trace
-// kernel.  The camera table lives in the scene, so one scene carries one trace at a time.
+// kernel.  d_camtab (scene->n_padded entries) belongs to the caller's job or workspace, so one scene carries any
+// number of traces at a time.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
                  float * d_partial, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, size_t capacity, const uint32_t * d_cancel = nullptr,
-                 f4 * d_camtab = nullptr)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, size_t capacity, const uint32_t * d_cancel, f4 * d_camtab)
 {
-  if (d_camtab == nullptr)
-    d_camtab = scene->d_camtab;  // one trace at a time per scene then
   TraceArgs a;
   std::memset(&a, 0, sizeof(a));
   prepare_frame(*camera, *p, a);
@@ -996,6 +1026,11 @@ void destroy_job(rt_hip_job * job)
   if (job->d_partial) (void)hipFree(job->d_partial);
   if (job->d_planes) (void)hipFree(job->d_planes);
   if (job->d_rgb) (void)hipFree(job->d_rgb);
+  if (job->d_camtab) (void)hipFree(job->d_camtab);
+  if (job->d_snap_planes) (void)hipFree(job->d_snap_planes);
+  if (job->d_snap_rgb) (void)hipFree(job->d_snap_rgb);
+  if (job->h_snap) (void)hipHostFree(job->h_snap);
+  if (job->done) (void)hipEventDestroy(job->done);
   if (job->d_stats) (void)hipFree(job->d_stats);
   if (job->h_cancel) (void)hipHostFree(job->h_cancel);
   if (job->start) (void)hipEventDestroy(job->start);
@@ -1012,8 +1047,8 @@ void free_job(rt_hip_job * job)
   rt_hip_job * evicted = job;
   {
     std::lock_guard<std::mutex> lock(g_lib.mutex);
-    if (g_lib.ready && job->d_partial && job->d_planes && job->d_rgb && job->d_stats && job->h_cancel && job->start &&
-        job->stop)
+    if (g_lib.ready && job->d_partial && job->d_planes && job->d_rgb && job->d_camtab && job->d_stats &&
+        job->h_cancel && job->start && job->stop && job->done)
     {
       evicted = g_lib.spare_job;
       g_lib.spare_job = job;
@@ -1023,14 +1058,16 @@ void free_job(rt_hip_job * job)
 }
 
 // A job object with buffers for `params`: the spare one if it fits, else a fresh one.
-rt_hip_job * acquire_job(const rt_hip_trace_params * params, hipError_t & e)
+rt_hip_job * acquire_job(const rt_hip_trace_params * params, size_t camtab_entries, hipError_t & e)
 {
   size_t const need = trace_buffer_bytes(params);
   size_t const pixels = (size_t)params->width * params->height;
+  camtab_entries = std::max<size_t>(camtab_entries, 1);
   rt_hip_job * job = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_lib.mutex);
-    if (g_lib.spare_job != nullptr && g_lib.spare_job->partial_size >= need && g_lib.spare_job->pixels == pixels)
+    if (g_lib.spare_job != nullptr && g_lib.spare_job->partial_size >= need && g_lib.spare_job->pixels == pixels &&
+        g_lib.spare_job->camtab_entries >= camtab_entries)
     {
       job = g_lib.spare_job;
       g_lib.spare_job = nullptr;
@@ -1053,7 +1090,10 @@ rt_hip_job * acquire_job(const rt_hip_trace_params * params, hipError_t & e)
   job->params = *params;
   job->partial_size = need;
   job->pixels = pixels;
+  job->camtab_entries = camtab_entries;
   e = hipMalloc((void **)&job->d_partial, std::max<size_t>(need, 16));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_camtab, camtab_entries * sizeof(f4));
+  if (e == hipSuccess) e = hipEventCreate(&job->done);
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_rgb, 3 * pixels * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
@@ -1073,6 +1113,33 @@ rt_hip_job * acquire_job(const rt_hip_trace_params * params, hipError_t & e)
 
 extern "C" {
 
+// Everything the library owns on g_lib.device (that device must be current; g_lib.mutex held): streams, the spare
+// job, the per-stream workspaces, the cancel word and the jitter table.  Scenes and running jobs belong to the
+// caller.
+static void release_device_state()
+{
+  if (g_lib.stream) (void)hipStreamSynchronize(g_lib.stream);
+  if (g_lib.copy_stream) (void)hipStreamSynchronize(g_lib.copy_stream);
+  if (g_lib.stream) (void)hipStreamDestroy(g_lib.stream);
+  if (g_lib.copy_stream) (void)hipStreamDestroy(g_lib.copy_stream);
+  g_lib.stream = nullptr;
+  g_lib.copy_stream = nullptr;
+  destroy_job(g_lib.spare_job);
+  g_lib.spare_job = nullptr;
+  for (Library::Workspace & w : g_lib.workspaces)
+  {
+    if (w.partial) (void)hipFree(w.partial);
+    if (w.camtab) (void)hipFree(w.camtab);
+    if (w.stats) (void)hipFree(w.stats);
+    w = Library::Workspace();
+  }
+  if (g_lib.never_cancel) (void)hipFree(g_lib.never_cancel);
+  if (g_lib.jitter_tab) (void)hipFree(g_lib.jitter_tab);
+  g_lib.never_cancel = nullptr;
+  g_lib.jitter_tab = nullptr;
+  g_lib.ready = false;
+}
+
 int rt_hip_init(int device)
 {
   std::lock_guard<std::mutex> lock(g_lib.mutex);
@@ -1080,41 +1147,48 @@ int rt_hip_init(int device)
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0)
     return fail(RT_HIP_ERR_DEVICE, "no HIP device available", e);
-  if (device >= 0)
+  if (device >= count)
+    return fail(RT_HIP_ERR_INVALID, "device index out of range");
+  int target = device;
+  if (target < 0)
+    RT_CHECK(hipGetDevice(&target));
+  if (g_lib.ready && g_lib.device == target)
   {
-    if (device >= count)
-      return fail(RT_HIP_ERR_INVALID, "device index out of range");
-    RT_CHECK(hipSetDevice(device));
-  }
-  int current = 0;
-  RT_CHECK(hipGetDevice(&current));
-  if (g_lib.ready && g_lib.device == current)
+    RT_CHECK(hipSetDevice(target));
     return RT_HIP_OK;
+  }
   if (g_lib.ready)
   {
-    (void)hipStreamDestroy(g_lib.stream);
-    (void)hipStreamDestroy(g_lib.copy_stream);
-    g_lib.ready = false;
+    // Another device: what was allocated on the old one is released there, not carried over (kernels on the new
+    // device could not read it).
+    RT_CHECK(hipSetDevice(g_lib.device));
+    release_device_state();
   }
+  if (g_lib.stream || g_lib.copy_stream || g_lib.never_cancel || g_lib.jitter_tab)
+  {
+    // an earlier rt_hip_init failed half way
+    RT_CHECK(hipSetDevice(g_lib.device));
+    release_device_state();
+  }
+  RT_CHECK(hipSetDevice(target));
   hipDeviceProp_t prop;
-  RT_CHECK(hipGetDeviceProperties(&prop, current));
-  g_lib.device = current;
+  RT_CHECK(hipGetDeviceProperties(&prop, target));
+  g_lib.device = target;
   g_lib.compute_units = prop.multiProcessorCount;
   g_lib.clock_khz = prop.clockRate;
+  // 64 KB is what a block gets without raising the kernel's dynamic-LDS attribute; the tiled layout with path
+  // stacks (61 KB) fits it, and a resident scene that would not is traced through tiles instead.
+  g_lib.lds_per_block = std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536u, 65536u);
   std::snprintf(g_lib.name, sizeof(g_lib.name), "%s (%s)", prop.name, prop.gcnArchName);
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.copy_stream, hipStreamNonBlocking));
-  if (g_lib.never_cancel == nullptr)
+  RT_CHECK(hipMalloc((void **)&g_lib.never_cancel, 64));
+  RT_CHECK(hipMemset(g_lib.never_cancel, 0, 64));
   {
-    RT_CHECK(hipMalloc((void **)&g_lib.never_cancel, 64));
-    RT_CHECK(hipMemset(g_lib.never_cancel, 0, 64));
-  }
-  if (g_lib.jitter_tab == nullptr)
-  {
-    std::vector<float> tab(RT_JITTER_FLOATS);
-    build_jitter_table(tab.data());
-    RT_CHECK(hipMalloc((void **)&g_lib.jitter_tab, tab.size() * sizeof(float)));
-    RT_CHECK(hipMemcpy(g_lib.jitter_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    float tab[RT_JITTER_FLOATS];
+    build_jitter_table(tab);
+    RT_CHECK(hipMalloc((void **)&g_lib.jitter_tab, sizeof(tab)));
+    RT_CHECK(hipMemcpy(g_lib.jitter_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
   g_lib.ready = true;
   return RT_HIP_OK;
@@ -1125,25 +1199,11 @@ void rt_hip_shutdown(void)
   std::lock_guard<std::mutex> lock(g_lib.mutex);
   if (!g_lib.ready)
     return;
-  (void)hipStreamSynchronize(g_lib.stream);
-  (void)hipStreamSynchronize(g_lib.copy_stream);
-  (void)hipStreamDestroy(g_lib.stream);
-  (void)hipStreamDestroy(g_lib.copy_stream);
-  destroy_job(g_lib.spare_job);
-  g_lib.spare_job = nullptr;
-  for (Library::Workspace & w : g_lib.workspaces)
-  {
-    if (w.partial) (void)hipFree(w.partial);
-    if (w.camtab) (void)hipFree(w.camtab);
-    if (w.stats) (void)hipFree(w.stats);
-    w = Library::Workspace();
-  }
-  g_lib.stream = nullptr;
-  g_lib.copy_stream = nullptr;
-  g_lib.ready = false;
+  (void)hipSetDevice(g_lib.device);
+  release_device_state();
 }
 
-const char * rt_hip_last_error(void) { return g_error.c_str(); }
+const char * rt_hip_last_error(void) { return g_error; }
 
 int rt_hip_device_info(int * compute_units, int * clock_khz, char * name, size_t name_len)
 {
@@ -1207,8 +1267,6 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   if (e == hipSuccess)
     e = upload((void **)&s->d_filter, fs.filter.data(), fs.filter.size() * sizeof(f4));
   if (e == hipSuccess)
-    e = hipMalloc((void **)&s->d_camtab, std::max<size_t>(fs.spheres.size() * sizeof(f4), 16));
-  if (e == hipSuccess)
     e = upload((void **)&s->d_sphere_mat, fs.sphere_mat.data(), fs.sphere_mat.size() * sizeof(uint32_t));
   if (e == hipSuccess)
     e = upload((void **)&s->d_materials, fs.materials.data(), fs.materials.size() * sizeof(f4));
@@ -1250,7 +1308,6 @@ void rt_hip_scene_destroy(rt_hip_scene * scene)
     return;
   if (scene->d_spheres) (void)hipFree(scene->d_spheres);
   if (scene->d_filter) (void)hipFree(scene->d_filter);
-  if (scene->d_camtab) (void)hipFree(scene->d_camtab);
   if (scene->d_sphere_mat) (void)hipFree(scene->d_sphere_mat);
   if (scene->d_materials) (void)hipFree(scene->d_materials);
   if (scene->d_lights) (void)hipFree(scene->d_lights);
@@ -1271,7 +1328,7 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
     return rc;
 
   hipError_t e = hipSuccess;
-  rt_hip_job * job = acquire_job(params, e);
+  rt_hip_job * job = acquire_job(params, scene->n_padded, e);
   if (job == nullptr)
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   uint32_t * d_cancel = nullptr;
@@ -1284,7 +1341,16 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   }
   rc = launch_trace(scene, camera, params, job->d_partial, job->d_stats, true, g_lib.stream, job->start,
-                    job->stop, job->partial_size, d_cancel);
+                    job->stop, job->partial_size, d_cancel, job->d_camtab);
+  // The accumulate and resolve passes follow the trace on its stream, so the image is complete when `done` fires
+  // and rt_hip_job_finish only has the download left -- on the copy stream, where it runs beside whatever frame
+  // the trace stream has started next.
+  if (rc == RT_HIP_OK)
+    rc = launch_colsum(job->d_partial, job->d_planes, params, g_lib.stream);
+  if (rc == RT_HIP_OK)
+    rc = launch_resolve(job->d_planes, job->d_rgb, params->width, params->height, params->samples_in_row, g_lib.stream);
+  if (rc == RT_HIP_OK && (e = hipEventRecord(job->done, g_lib.stream)) != hipSuccess)
+    rc = fail(RT_HIP_ERR_DEVICE, "hipEventRecord", e);
   if (rc != RT_HIP_OK)
   {
     (void)hipStreamSynchronize(g_lib.stream);
@@ -1299,7 +1365,7 @@ int rt_hip_job_poll(rt_hip_job * job)
 {
   if (job == nullptr)
     return fail(RT_HIP_ERR_INVALID, "null job");
-  hipError_t const e = hipEventQuery(job->stop);
+  hipError_t const e = hipEventQuery(job->done);
   if (e == hipSuccess)
     return RT_HIP_OK;
   if (e == hipErrorNotReady)
@@ -1312,22 +1378,32 @@ int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
   if (job == nullptr || rgb == nullptr)
     return fail(RT_HIP_ERR_INVALID, "null argument");
   size_t const pixels = (size_t)job->params.width * job->params.height;
-  std::vector<float> planes(3 * pixels);
-  // Accumulate + copy on their own stream: they run beside the trace kernel and never wait for it.  Columns
-  // the trace has not finished yet still hold the zeros they were cleared to.
-  int const rc = launch_colsum(job->d_partial, job->d_planes, &job->params, g_lib.copy_stream);
+  size_t const bytes = 3 * pixels * sizeof(float);
+  if (job->h_snap == nullptr)
+  {
+    hipError_t e = hipMalloc((void **)&job->d_snap_planes, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&job->d_snap_rgb, bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&job->h_snap, bytes, hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+      if (job->d_snap_planes) (void)hipFree(job->d_snap_planes);
+      if (job->d_snap_rgb) (void)hipFree(job->d_snap_rgb);
+      job->d_snap_planes = job->d_snap_rgb = nullptr;
+      job->h_snap = nullptr;
+      return fail(RT_HIP_ERR_DEVICE, "snapshot buffers", e);
+    }
+  }
+  // Accumulate, resolve and download on the copy stream: they run beside the trace kernel and never wait for it.
+  // Columns the trace has not finished yet still hold the zeros they were cleared to.
+  int rc = launch_colsum(job->d_partial, job->d_snap_planes, &job->params, g_lib.copy_stream);
+  if (rc == RT_HIP_OK)
+    rc = launch_resolve(job->d_snap_planes, job->d_snap_rgb, job->params.width, job->params.height,
+                        job->params.samples_in_row, g_lib.copy_stream);
   if (rc != RT_HIP_OK)
     return rc;
-  RT_CHECK(hipMemcpyAsync(planes.data(), job->d_planes, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost,
-                          g_lib.copy_stream));
+  RT_CHECK(hipMemcpyAsync(job->h_snap, job->d_snap_rgb, bytes, hipMemcpyDeviceToHost, g_lib.copy_stream));
   RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
-  float const inv = 1.0f / static_cast<float>(job->params.samples_in_row * job->params.samples_in_row);
-  for (size_t i = 0; i < pixels; ++i)
-  {
-    rgb[3 * i + 0] = planes[i] * inv;
-    rgb[3 * i + 1] = planes[pixels + i] * inv;
-    rgb[3 * i + 2] = planes[2 * pixels + i] * inv;
-  }
+  std::memcpy(rgb, job->h_snap, bytes);
   return RT_HIP_OK;
 }
 
@@ -1347,30 +1423,26 @@ int rt_hip_job_finish(rt_hip_job * job, float * rgb, rt_hip_stats * stats)
   if (job == nullptr)
     return fail(RT_HIP_ERR_INVALID, "null job");
   int rc = RT_HIP_OK;
-  hipError_t e = hipEventSynchronize(job->stop);
+  hipError_t e = hipEventSynchronize(job->done);
   if (e != hipSuccess)
     rc = fail(RT_HIP_ERR_DEVICE, "hipEventSynchronize", e);
   size_t const pixels = (size_t)job->params.width * job->params.height;
   if (rc == RT_HIP_OK && rgb != nullptr)
   {
-    rc = launch_colsum(job->d_partial, job->d_planes, &job->params, g_lib.stream);
-    if (rc == RT_HIP_OK)
-      rc = launch_resolve(job->d_planes, job->d_rgb, job->params.width, job->params.height,
-                          job->params.samples_in_row, g_lib.stream);
-    if (rc == RT_HIP_OK)
-    {
-      e = hipMemcpyAsync(rgb, job->d_rgb, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost, g_lib.stream);
-      if (e == hipSuccess)
-        e = hipStreamSynchronize(g_lib.stream);
-      if (e != hipSuccess)
-        rc = fail(RT_HIP_ERR_DEVICE, "image download", e);
-    }
+    // The image is complete (`done`); its download does not queue behind the next frame's trace.
+    e = hipMemcpyAsync(rgb, job->d_rgb, 3 * pixels * sizeof(float), hipMemcpyDeviceToHost, g_lib.copy_stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(g_lib.copy_stream);
+    if (e != hipSuccess)
+      rc = fail(RT_HIP_ERR_DEVICE, "image download", e);
   }
   if (rc == RT_HIP_OK && stats != nullptr)
   {
     unsigned long long h[kStatsWords] = {0};
     std::memset(stats, 0, sizeof(*stats));
-    e = hipMemcpy(h, job->d_stats, sizeof(h), hipMemcpyDeviceToHost);
+    e = hipMemcpyAsync(h, job->d_stats, sizeof(h), hipMemcpyDeviceToHost, g_lib.copy_stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(g_lib.copy_stream);
     if (e == hipSuccess)
     {
       read_stats(h, stats);
@@ -1398,32 +1470,31 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
     return fail(RT_HIP_ERR_INVALID, "null output");
   hipStream_t const hs = static_cast<hipStream_t>(stream);
   // This stream's workspace: calls on one stream are ordered and share it, calls on different streams overlap.
+  // The lock is held until the work is enqueued, so a workspace cannot change hands under a call that uses it.
+  std::lock_guard<std::mutex> lock(g_lib.mutex);
   Library::Workspace * ws = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_lib.mutex);
-    for (Library::Workspace & w : g_lib.workspaces)
-      if (w.used && w.stream == hs)
-        ws = &w;
-    for (Library::Workspace & w : g_lib.workspaces)
-      if (ws == nullptr && !w.used)
-      {
-        w.used = true;
-        w.stream = hs;
-        ws = &w;
-      }
-    if (ws == nullptr)
+  for (Library::Workspace & w : g_lib.workspaces)
+    if (w.used && w.stream == hs)
+      ws = &w;
+  for (Library::Workspace & w : g_lib.workspaces)
+    if (ws == nullptr && !w.used)
     {
-      // every set belongs to some stream: the least recently used one changes hands once the device is idle
-      // (its old stream may no longer exist, so there is nothing narrower to wait for)
-      ws = &g_lib.workspaces[0];
-      for (Library::Workspace & w : g_lib.workspaces)
-        if (w.last_use < ws->last_use)
-          ws = &w;
-      RT_CHECK(hipDeviceSynchronize());
-      ws->stream = hs;
+      w.used = true;
+      w.stream = hs;
+      ws = &w;
     }
-    ws->last_use = ++g_lib.workspace_clock;
+  if (ws == nullptr)
+  {
+    // every set belongs to some stream: the least recently used one changes hands once the device is idle
+    // (its old stream may no longer exist, so there is nothing narrower to wait for)
+    ws = &g_lib.workspaces[0];
+    for (Library::Workspace & w : g_lib.workspaces)
+      if (w.last_use < ws->last_use)
+        ws = &w;
+    RT_CHECK(hipDeviceSynchronize());
+    ws->stream = hs;
   }
+  ws->last_use = ++g_lib.workspace_clock;
   size_t const need = trace_buffer_bytes(params);
   if (ws->partial_bytes < need)
   {
@@ -1485,8 +1556,10 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
     return fail(RT_HIP_ERR_INVALID, "bad argument");
   float * d_planes = nullptr;  // column sums
   unsigned long long * d_stats = nullptr;
+  f4 * d_camtab = nullptr;
   hipEvent_t start = nullptr, stop = nullptr;
   hipError_t e = hipMalloc((void **)&d_planes, trace_buffer_bytes(params));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_camtab, sizeof(f4) * std::max<size_t>(scene->n_padded, 1));
   if (e == hipSuccess) e = hipMalloc((void **)&d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
   if (e == hipSuccess) e = hipEventCreate(&start);
   if (e == hipSuccess) e = hipEventCreate(&stop);
@@ -1494,7 +1567,7 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
   for (uint32_t i = 0; e == hipSuccess && rc == RT_HIP_OK && i < launches; ++i)
   {
     rc = launch_trace(scene, camera, params, d_planes, d_stats, true, g_lib.stream, start, stop,
-                      trace_buffer_bytes(params));
+                      trace_buffer_bytes(params), nullptr, d_camtab);
     if (rc != RT_HIP_OK)
       break;
     e = hipEventSynchronize(stop);
@@ -1521,6 +1594,7 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
   }
   if (d_planes) (void)hipFree(d_planes);
   if (d_stats) (void)hipFree(d_stats);
+  if (d_camtab) (void)hipFree(d_camtab);
   if (start) (void)hipEventDestroy(start);
   if (stop) (void)hipEventDestroy(stop);
   if (e != hipSuccess)

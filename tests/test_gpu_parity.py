@@ -3,8 +3,9 @@
 Tolerances:
   * deterministic mode (no stochastic scattering): every pixel within 1e-4 relative (floor 1e-3 absolute
     radiance in the denominator) of the CPU path;
-  * stochastic mode, same Philox streams on both sides: mean absolute error below 1e-4 and at most 0.5 % of
-    the pixels off by more than 1e-3 relative (pixels where a last-bit difference flips a branch);
+  * stochastic mode, same Philox streams on both sides: mean absolute error below 5e-6 and at most 0.1 % of
+    the pixels off by more than 1e-3 relative (pixels where a last-bit difference flips a branch; measured at
+    640x480 4x4: 1.6e-7 and 0.007 %);
   * converged renders (144 samples per pixel) with different seeds: PSNR above 35 dB, mean absolute error
     within 1.25x of what two CPU renders with different seeds differ by, mean radiance within 1e-3.
 """
@@ -63,13 +64,13 @@ def test_ragged_frame_shapes(hip, oracle, ffi, scenes, w, h, s):
 @pytest.mark.parametrize("demo", [1, 2], ids=["pretty", "glass"])
 def test_stochastic_mode_shares_the_random_streams(hip, oracle, ffi, scenes, demo):
     scene = scenes(demo)
-    p = ffi.params(160, 120, 3, seed=7)
+    p = ffi.params(320, 240, 3, seed=7)
     ref, rs = oracle.render(scene, p)
     out, st = hip.render(scene, p)
-    assert np.abs(ref - out).mean() < 1e-4
-    assert (rel_err(ref, out).max(axis=2) > 1e-3).mean() < 5e-3
+    assert np.abs(ref - out).mean() < 5e-6
+    assert (rel_err(ref, out).max(axis=2) > 1e-3).mean() < 1e-3
     assert st.samples == rs.samples
-    assert abs(int(st.ray_queries) - int(rs.ray_queries)) < 1e-3 * rs.ray_queries
+    assert abs(int(st.ray_queries) - int(rs.ray_queries)) < 1e-4 * rs.ray_queries
 
 
 @pytest.mark.parametrize("demo", [1, 2], ids=["pretty", "glass"])
