@@ -30,6 +30,7 @@
  *     Different jobs may be started and finished from different threads; they run on the library's trace stream
  *     in the order they were started.
  *   - rt_hip_trace_device may be called from several threads (one caller stream each).
+ *   - rt_hip_trace_device_static shares one scratch array per GPU: calls that overlap on one GPU race.
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -185,6 +186,19 @@ int rt_hip_job_cancel(rt_hip_job * job);
 int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera,
                         const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
                         void * stream);
+
+/* rt_hip_trace_device without any allocation.  No counterpart in the reference: it is for callers that cannot
+ * call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * arguments, same output (bit for bit) as rt_hip_trace_device, but the scratch the kernels need (counters, camera
+ * table, column sums, sample-sharing room) is a 64 MiB file-scope device array of the library instead of a
+ * workspace: width * height * samples_in_row may not exceed 5 570 538 (12 bytes per sub-sample column; e.g.
+ * 1024 x 768 at 2 x 2 ... 7 x 7 samples per pixel, or 1920 x 1080 at 2 x 2) and the scene may have at most 16384
+ * spheres -- RT_HIP_ERR_INVALID with a message naming the limit otherwise.  Every call on a GPU uses that GPU's
+ * one array, so calls that overlap on one GPU (on different streams or from different threads) race; calls on
+ * one stream are ordered and safe.  Calls no hipMalloc / hipFree / hipHostMalloc. */
+int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                               const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
+                               void * stream);
 
 /* The accumulate/resolve pass: d_rgb[p*3+c] = d_sum_planes[c*h*w + p] * (1 / S^2)
  * (ray_tracing/frame.cpp:43,67), planar sums -> interleaved image, on `stream`. */

@@ -60,6 +60,24 @@ constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS
 constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
 constexpr uint32_t kStatsWords = 8;
 
+// ---- rt_hip_trace_device_static: the one entry point that allocates nothing ----
+// Its scratch (counters, camera table, column sums, sample-sharing room) is this file-scope array instead of a
+// workspace from hipMalloc.  Every GPU the library runs on holds its own copy, at its own address, until the
+// process ends; host code never uses the array's name as an address, only the per-device pointer that
+// hipGetSymbolAddress returns (resolve_static_scratch).  Layout:
+//   [0, 256)                         counters + queue word, for callers that pass no d_stats
+//   [256, 256 + 16 * kStaticMaxSpheres)  camera table
+//   [kStaticPartialOffset, end)      column sums (12 bytes per column of the frame), then, if it still fits,
+//                                    the records and colours of sample sharing
+constexpr size_t kStaticScratchBytes = (size_t)64u << 20;  // 64 MiB per GPU
+constexpr uint32_t kStaticMaxSpheres = 16384;
+constexpr size_t kStaticCamtabOffset = 256;
+constexpr size_t kStaticPartialOffset = kStaticCamtabOffset + sizeof(f4) * (size_t)kStaticMaxSpheres;
+constexpr size_t kStaticPartialBytes = kStaticScratchBytes - kStaticPartialOffset;
+static_assert(kStaticPartialOffset % 256u == 0u, "the column sums start on a 256-byte boundary");
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 // ---------------------------------------------------------------- device side
 
 // Work items come from one frame-wide counter, but a wave only touches it once per A.batch_items items (a
@@ -660,6 +678,8 @@ struct Library
   unsigned long long workspace_clock = 0;
   static constexpr int kWorkspaces = 8;
   Workspace workspaces[kWorkspaces];
+  // Device address of `scratch` on each device the library has been initialised on (nullptr: not resolved yet).
+  unsigned char * static_scratch[kMaxDevices] = {nullptr};
   uint32_t * never_cancel = nullptr;  // a zero word for traces that cannot be cancelled
   float * jitter_tab = nullptr;       // RT_JITTER_FLOATS, see rt_core.h jitter_ball
   rt_hip_job * spare_job = nullptr;   // buffers of the last finished job, see free_job
@@ -1140,6 +1160,19 @@ static void release_device_state()
   g_lib.ready = false;
 }
 
+// The address of the file-scope scratch array on the current device, once per device.
+static int resolve_static_scratch(int device)
+{
+  if (device < 0 || device >= kMaxDevices)
+    return RT_HIP_OK;  // rt_hip_trace_device_static reports the missing address when it is asked for
+  if (g_lib.static_scratch[device] != nullptr)
+    return RT_HIP_OK;
+  void * ptr = nullptr;
+  RT_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  g_lib.static_scratch[device] = static_cast<unsigned char *>(ptr);
+  return RT_HIP_OK;
+}
+
 int rt_hip_init(int device)
 {
   std::lock_guard<std::mutex> lock(g_lib.mutex);
@@ -1190,6 +1223,9 @@ int rt_hip_init(int device)
     RT_CHECK(hipMalloc((void **)&g_lib.jitter_tab, sizeof(tab)));
     RT_CHECK(hipMemcpy(g_lib.jitter_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
+  int const rc = resolve_static_scratch(target);
+  if (rc != RT_HIP_OK)
+    return rc;
   g_lib.ready = true;
   return RT_HIP_OK;
 }
@@ -1532,6 +1568,45 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
                          ws->partial_bytes, nullptr, ws->camtab);
   if (rc2 == RT_HIP_OK)
     rc2 = launch_colsum(ws->partial, d_sum_planes, params, hs);
+  return rc2;
+}
+
+int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                               const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
+                               void * stream)
+{
+  int const rc = validate(scene, camera, params);
+  if (rc != RT_HIP_OK)
+    return rc;
+  if (d_sum_planes == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null output");
+  unsigned char * const base =
+      (g_lib.device >= 0 && g_lib.device < kMaxDevices) ? g_lib.static_scratch[g_lib.device] : nullptr;
+  if (base == nullptr)
+    return fail(RT_HIP_ERR_DEVICE, "the static scratch array has no address on this device");
+  if (scene->n_padded > kStaticMaxSpheres)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_trace_device_static takes scenes of at most 16384 spheres");
+  if (partial_bytes(params) > kStaticPartialBytes)
+  {
+    char msg[256];
+    std::snprintf(msg, sizeof(msg),
+                  "rt_hip_trace_device_static: width * height * samples_in_row is %llu, the limit is %llu (12 bytes per "
+                  "sub-sample column in a 64 MiB static array); rt_hip_trace_device has no such limit",
+                  frame_items(params), (unsigned long long)(kStaticPartialBytes / (3u * sizeof(float))));
+    return fail(RT_HIP_ERR_INVALID, msg);
+  }
+  hipStream_t const hs = static_cast<hipStream_t>(stream);
+  unsigned long long * const st =
+      d_stats ? static_cast<unsigned long long *>(d_stats) : reinterpret_cast<unsigned long long *>(base);
+  f4 * const camtab = reinterpret_cast<f4 *>(base + kStaticCamtabOffset);
+  float * const partial = reinterpret_cast<float *>(base + kStaticPartialOffset);
+  // Nothing in the array has to be cleared by the host: the set-up kernel zeroes the counters, the queue word and the
+  // sharing record count on the stream, every column sum of the frame is written by exactly one lane, and the
+  // camera table is rewritten for this frame.  Sample sharing is on when its room fits behind the column sums.
+  int rc2 = launch_trace(scene, camera, params, partial, st, d_stats != nullptr, hs, nullptr, nullptr,
+                         kStaticPartialBytes, nullptr, camtab);
+  if (rc2 == RT_HIP_OK)
+    rc2 = launch_colsum(partial, d_sum_planes, params, hs);
   return rc2;
 }
 

@@ -98,6 +98,10 @@ HIP_SYMBOLS = {
         C.c_int,
         [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "rt_hip_trace_device_static": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "rt_hip_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rt_hip_time_trace_kernel": (
         C.c_int,
@@ -325,6 +329,14 @@ class HipRenderer:
             self.lib.rt_hip_trace_device(self.upload(scene), C.byref(scene.camera), C.byref(p), d_planes_ptr,
                                          d_stats_ptr, stream_ptr),
             "rt_hip_trace_device",
+        )
+
+    def trace_device_static(self, scene, p, d_planes_ptr, d_stats_ptr=None, stream_ptr=None):
+        """rt_hip_trace_device over the library's static scratch array: allocates nothing, bounded frame size."""
+        self._check(
+            self.lib.rt_hip_trace_device_static(self.upload(scene), C.byref(scene.camera), C.byref(p), d_planes_ptr,
+                                                d_stats_ptr, stream_ptr),
+            "rt_hip_trace_device_static",
         )
 
     def resolve_device(self, d_planes_ptr, d_rgb_ptr, p, stream_ptr=None):

@@ -1,0 +1,68 @@
+"""rt_hip_trace_device_static -- the entry point that allocates nothing -- against rt_hip_trace_device.
+
+Both take the same arguments and must write the same sum planes and counters, bit for bit; the static variant
+keeps its scratch in a file-scope device array of the library, so its frame size is bounded and consecutive
+calls reuse (and must not be confused by) what the previous call left there.
+"""
+import ctypes as C
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_static_scratch_entry_point_matches_the_allocating_one(hip, ffi, scenes):
+    import torch
+
+    stream = torch.cuda.current_stream().cuda_stream
+    # two calls in a row, the second with a smaller frame (and another scene, seed and a slice)
+    cases = [
+        (scenes(1), ffi.params(1024, 768, 2, seed=3)),
+        (scenes(2), ffi.params(320, 200, 3, seed=9, slice_index=1, slice_count=2)),
+    ]
+    expected = []
+    for scene, p in cases:
+        n = 3 * p.width * p.height
+        planes = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+        stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+        hip.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
+        torch.cuda.synchronize()
+        expected.append((planes, stats[:6].clone()))
+    outputs = [torch.full((3 * p.width * p.height,), float("nan"), dtype=torch.float32, device="cuda") for _, p in cases]
+    counters = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in cases]
+    for scene, _ in cases:
+        hip.upload(scene)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for (scene, p), out, st in zip(cases, outputs, counters):
+        hip.trace_device_static(scene, p, out.data_ptr(), st.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before  # nothing was allocated on the device
+    for (want, want_stats), out, st in zip(expected, outputs, counters):
+        assert torch.equal(out, want)
+        assert torch.equal(st[:6], want_stats)
+    # the first frame again after the smaller one, this time with the counters in the scratch array
+    again = torch.full_like(outputs[0], float("nan"))
+    hip.trace_device_static(cases[0][0], cases[0][1], again.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(again, expected[0][0])
+
+
+def test_static_scratch_entry_point_refuses_what_does_not_fit(hip, ffi, scenes):
+    import torch
+
+    scene = scenes(1)
+    handle = hip.upload(scene)
+    planes = torch.empty(3 * 1920 * 1080, dtype=torch.float32, device="cuda")
+    too_big = ffi.params(1920, 1080, 16)
+    rc = hip.lib.rt_hip_trace_device_static(handle, C.byref(scene.camera), C.byref(too_big), planes.data_ptr(), None, None)
+    assert rc == 1
+    message = hip.lib.rt_hip_last_error()
+    assert b"limit is 5570538" in message and b"33177600" in message
+    fits = ffi.params(1920, 1080, 2, seed=1)  # 4.1 M columns
+    hip.trace_device_static(scene, fits, planes.data_ptr(), None, None)
+    torch.cuda.synchronize()
+    want = torch.empty_like(planes)
+    hip.trace_device(scene, fits, want.data_ptr(), None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(planes, want)
