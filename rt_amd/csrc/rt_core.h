@@ -13,10 +13,13 @@
 //
 // Ray against all spheres, in two steps:
 //   filter   a ray from O along unit D can only hit sphere (C, r) in front of O if
-//            dot(O - C, D) <= -sqrt(|O - C|^2 - r^2).  The right-hand side depends on the origin only, so
-//            it is computed once per sphere for the six rays of a pass (and once per frame for the
-//            camera); each ray-sphere test is then 3 FMAs, a compare and an add-with-carry that shifts
-//            the result into a per-lane candidate mask.  A small margin keeps the filter conservative.
+//            dot(C - O, D) >= sqrt(|O - C|^2 - r^2).  The right-hand side depends on the origin only, so
+//            it is computed once per sphere for the rays of a pass (and once per frame for the camera); a
+//            ray-sphere test is then 3 FMAs and one instruction that shifts the sign of the result into a
+//            per-lane candidate mask.  A small margin keeps the filter conservative.  The five shadow rays
+//            of a light all lie in a narrow cone around the direction to the light, so a pass tests that
+//            cone once per sphere (same cost as one ray) and only the spheres the cone may touch are then
+//            tested against the five rays one by one.
 //   resolve  the few candidates are intersected exactly as Sphere::TraceNearest does
 //            (ray_tracing/sphere.cpp:63-81), operation for operation, with IEEE sqrt and division and
 //            without FMA contraction, keeping the nearest one as TraceNearestInHitableCollection does
@@ -54,6 +57,7 @@ constexpr float RT_EPS = 1e-5f;        // ray_tracing/types.hpp:9
 constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
 constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
+constexpr uint32_t RT_LIGHT_RECORDS = 3; // float4 records per light
 constexpr uint32_t RT_UNROLL = 2;      // camera-table entries per trip of the primary filter's main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
@@ -217,15 +221,19 @@ struct TraceArgs
 {
   // scene, device memory
   const f4 * spheres;          // n_padded x (cx, cy, cz, r*r): what the exact intersection reads
-  const f4 * filter;           // n_padded x (cx, cy, cz, r*r widened by the filter margin)
+  const f4 * filter;           // n_padded x (cx, cy, cz, radius widened by the filter margin)
   const f4 * camtab;           // n_padded x (centre - camera, filter bound): the primary-ray filter
   const uint32_t * sphere_mat; // n_spheres
   const f4 * materials;        // n_materials x RT_MAT_RECORDS: (albedo rgb, roughness), (refraction, type bits,
                                // f0^2, 1 / refraction), (r^2, 4 r^2, metal emissivity, 0) with r = max(roughness, 0.03)
-  const f4 * lights;           // n_lights x 2: (direction xyz, 0), (colour rgb, 0)
+  const f4 * lights;           // n_lights x RT_LIGHT_RECORDS: (direction xyz, cone cos), (colour rgb, cone sin),
+                               // (unit direction to the light, 0); the cone is that of the light's shadow rays,
+                               // see ShadowCone
   const float * jitter_tab;    // RT_JITTER_FLOATS, see jitter_ball
   uint32_t n_spheres, n_padded, n_materials, n_lights;  // n_padded: records in the sphere arrays (= n_spheres)
-  uint32_t tile_size;          // filter records staged per tile when the scene is not resident 
+  uint32_t tile_size;          // filter records staged per tile when the scene is not resident
+  f3 cone_axis;                // ShadowCone of light 0, for kernels specialised for one light (wave-uniform there)
+  float cone_cos, cone_sin;
   // camera, precomputed on the host exactly as Frame::ForEachRayImpl does (ray_tracing/frame.cpp:33-41)
   f3 cam_pos, cam_dir, cam_right, cam_up, background;
   float znear, zfar, dw, dh, cell_x, cell_y;
@@ -276,7 +284,8 @@ struct TraceArgs
 struct LaneCounters
 {
   uint32_t samples, queries, hits, shaded, exact_tests;
-  uint32_t filter_tests;  // rays (or columns) run through the filter; each is n_spheres tests
+  uint32_t filter_tests;  // rays, shadow cones or columns run through the filter; each is n_spheres tests
+  uint32_t cone_tests;    // spheres a shadow cone touched: each was tested against the five shadow rays
   uint32_t trips, rounds;  // loop trips and stage-P rounds this lane sat through, busy or not
 #if defined(RT_PROFILE_REGIONS)
   // Profiling builds only: wave clock ticks spent in each region of the loop (see RT_REGION).
@@ -304,11 +313,12 @@ struct LaneCounters
 
 // The filter.  With d = C - O and unit D, the ray can hit the sphere in front of O only if
 // dot(d, D) >= sqrt(c), c = |d|^2 - r^2.  The bound is taken from c - m (|d|^2 + r^2), m = RT_FILTER_MARGIN
-// (the stored r2f is r^2 (1 + m)), so that rounding here (FMAs, approximate sqrt: a few ulps of |d|^2) can
-// never reject a ray the exact intersection would accept; an origin on or inside the widened sphere gives
-// bound 0.
-RT_FN float filter_bound(float dx, float dy, float dz, float r2f)
+// (the filter records hold the radius widened to rw >= r (1 + m), so rw^2 >= r^2 (1 + m)), so that rounding
+// here (FMAs, approximate sqrt: a few ulps of |d|^2) can never reject a ray the exact intersection would
+// accept; an origin on or inside the widened sphere gives bound 0.
+RT_FN float filter_bound(float dx, float dy, float dz, float rw)
 {
+  float const r2f = rw * rw;
   float const dd = hw_fma(dz, dz, hw_fma(dy, dy, dx * dx));
   // sqrt of a negative number is a NaN, which max() turns into the 0 wanted for an origin inside the sphere
   return hw_max(hw_sqrt(hw_fma(dd, (float)(1.0 - RT_FILTER_MARGIN), -r2f)), 0.0f);
@@ -693,35 +703,62 @@ RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
   return chunk_candidates(mask, count);
 }
 
-// One sphere against RT_RAYS rays with a common origin.
-RT_FN void filter_sphere_6(f4 s, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask)[RT_RAYS])
+// The cone that holds the shadow rays of one light.  DirectionalLight::TraceLight
+// (ray_tracing/directional_light.cpp:20) shoots along normalize(-L + ballRand(0.25)): every such direction is
+// within asin(0.25 / |L|) of the unit vector `axis` = -L / |L|.  A ray inside the cone can hit sphere (C, r) only
+// if the angle between d = C - O and the axis is at most theta + alpha, sin(alpha) = r / |d|, that is
+//   dot(d, axis) >= cos(theta) sqrt(|d|^2 - r^2) - sin(theta) r.
+// cos_m / sin_m are cos(theta) rounded down and sin(theta) rounded up by a thousandth (rt_prep.h shadow_cone), the
+// square root is the filter's own bound (already on the safe side) and r the widened radius, so whatever one of the
+// five per-ray tests or the exact intersection accepts, this accepts.  A light too short for a cone (|L| close to
+// the jitter radius) gets cos_m = 0, sin_m = 3e38: every sphere passes.
+struct ShadowCone
+{
+  f3 axis;
+  float cos_m, sin_m;
+};
+
+// One sphere against the shadow cone and the scattered ray of a pass (common origin o).
+RT_FN void filter_sphere_2(f4 s, f3 o, const ShadowCone & cone, f3 sdir, uint32_t & cone_mask, uint32_t & ray_mask)
 {
   float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
-  float const nb = -filter_bound(dx, dy, dz, s.w);
-#pragma unroll
-  for (int r = 0; r < RT_RAYS; ++r)
-    mask[r] = push_sign(mask[r], hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
+  float const bound = filter_bound(dx, dy, dz, s.w);
+  float const nb_cone = hw_fma(cone.sin_m, s.w, -(cone.cos_m * bound));
+  cone_mask = push_sign(cone_mask, hw_fma(dz, cone.axis.z, hw_fma(dy, cone.axis.y, hw_fma(dx, cone.axis.x, nb_cone))));
+  ray_mask = push_sign(ray_mask, hw_fma(dz, sdir.z, hw_fma(dy, sdir.y, hw_fma(dx, sdir.x, -bound))));
 }
 
-// Filter of RT_RAYS rays with a common origin against `count` (<= RT_CHUNK) spheres.
+// The shadow cone and the scattered ray against `count` (<= RT_CHUNK) spheres.
 template <uint32_t kUnroll>
-RT_FN void filter_chunk_6(const f4 * sph, uint32_t count, f3 o, const f3 (&dir)[RT_RAYS], uint32_t (&mask)[RT_RAYS])
+RT_FN void filter_chunk_2(const f4 * sph, uint32_t count, f3 o, const ShadowCone & cone, f3 sdir,
+                          uint32_t & cone_mask, uint32_t & ray_mask)
 {
-#pragma unroll
-  for (int r = 0; r < RT_RAYS; ++r)
-    mask[r] = 0;
+  cone_mask = 0;
+  ray_mask = 0;
   uint32_t j = 0;
   for (; j + kUnroll <= count; j += kUnroll)
   {
 #pragma unroll
     for (uint32_t u = 0; u < kUnroll; ++u)
-      filter_sphere_6(sph[j + u], o, dir, mask);
+      filter_sphere_2(sph[j + u], o, cone, sdir, cone_mask, ray_mask);
   }
   for (; j < count; ++j)
-    filter_sphere_6(sph[j], o, dir, mask);
+    filter_sphere_2(sph[j], o, cone, sdir, cone_mask, ray_mask);
+  cone_mask = chunk_candidates(cone_mask, count);
+  ray_mask = chunk_candidates(ray_mask, count);
+}
+
+// One sphere the cone may touch against the five shadow rays themselves: bit r of the result is set if ray r
+// passes the filter.
+RT_FN uint32_t filter_sphere_shadow(f4 s, f3 o, const f3 (&dir)[RT_RAYS])
+{
+  float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
+  float const nb = -filter_bound(dx, dy, dz, s.w);
+  uint32_t rejected = 0;
 #pragma unroll
-  for (int r = 0; r < RT_RAYS; ++r)
-    mask[r] = chunk_candidates(mask[r], count);
+  for (int r = RT_LIGHT_SAMPLES - 1; r >= 0; --r)
+    rejected = push_sign(rejected, hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
+  return ~rejected & ((1u << RT_LIGHT_SAMPLES) - 1u);
 }
 
 // Takes the candidate with the lowest sphere index out of a chunk mask; returns its index in the chunk.
@@ -948,10 +985,10 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
 }
 
 // rays_on: bit r set if ray r of this lane is to be traced.  Returns the shadow rays found occluded as bits
-// 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.
+// 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.  `cone` holds dir[0..4].
 template <bool kGrid, class Env>
 RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
-                          uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
+                          const ShadowCone & cone, uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
 {
   if constexpr (kGrid)
   {
@@ -971,6 +1008,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
   uint32_t live = rays_on;  // rays still looking for a hit
   near_i = -1;
   near_t = 0.0f;
+  constexpr uint32_t kShadowRays = (1u << RT_LIGHT_SAMPLES) - 1u;
   for (uint32_t k = 0; k < env.tiles(); ++k)
   {
     uint32_t const tile_count = env.load_tile(k, false);
@@ -979,10 +1017,33 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
     for (uint32_t c0 = 0; c0 < tile_count; c0 += RT_CHUNK)
     {
       uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
-      uint32_t mask[RT_RAYS];
+      uint32_t cone_mask, ray_mask;
       RT_REGION(cnt, 6);
-      filter_chunk_6<Env::kFilterUnroll>(sph + c0, count, o, dir, mask);
+      filter_chunk_2<Env::kFilterUnroll>(sph + c0, count, o, cone, dir[RT_RAYS - 1], cone_mask, ray_mask);
       RT_REGION(cnt, 7);
+      cone_mask = ((live & kShadowRays) != 0u) ? cone_mask : 0u;
+      ray_mask = ((live >> (RT_RAYS - 1)) & 1u) ? ray_mask : 0u;
+      if (!env.any_wave((cone_mask | ray_mask) != 0u))
+        continue;
+      // The spheres the cone may touch, against the five shadow rays themselves: one sphere per lane and
+      // iteration, no branches inside.
+      uint32_t mask[RT_RAYS];
+#pragma unroll
+      for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
+        mask[r] = 0u;
+      mask[RT_RAYS - 1] = ray_mask;
+      while (env.any_wave(cone_mask != 0u))
+      {
+        bool const h = cone_mask != 0u;
+        uint32_t m = h ? cone_mask : 1u;
+        uint32_t const bit = 31u - (uint32_t)hw_clz(m);
+        uint32_t const pass = h ? filter_sphere_shadow(sph[c0 + (count - 1u - bit)], o, dir) : 0u;
+        cnt.cone_tests += h ? 1u : 0u;
+#pragma unroll
+        for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
+          mask[r] |= ((pass >> r) & 1u) << bit;
+        cone_mask = h ? (m & ~(1u << bit)) : 0u;
+      }
       uint32_t any_mask = 0;
 #pragma unroll
       for (int r = 0; r < RT_RAYS; ++r)
@@ -1029,8 +1090,9 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       RT_REGION(cnt, 8);
     }
   }
-  cnt.filter_tests += (uint32_t)__builtin_popcount(rays_on);
-  return (rays_on & ~live) & ((1u << RT_LIGHT_SAMPLES) - 1u);
+  // tests run per sphere of the scene: the cone (once for the five shadow rays) and the scattered ray
+  cnt.filter_tests += ((rays_on & kShadowRays) != 0u ? 1u : 0u) + ((rays_on >> (RT_RAYS - 1)) & 1u);
+  return (rays_on & ~live) & kShadowRays;
 }
 
 // kOneLight: the scene has exactly one light, so a hit is shaded within one trip (one pass) and nothing of
@@ -1242,13 +1304,31 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     // from their stale (always initialised) state, and rays_on keeps those rays out of the trace.  That is
     // cheaper than a divergent region whose results must be merged with defaults.
     bool const lit = in_pass && L.li < n_lights;
+    ShadowCone cone;
     {
       uint32_t const li_c = (L.li < n_lights) ? L.li : 0u;
       f3 to_light = mk3(0.0f, 1.0f, 0.0f);
+      cone.axis = to_light;
+      cone.cos_m = 0.0f;
+      cone.sin_m = 3.0e38f;
       if (n_lights != 0u)
       {
         f4 const l0 = env.light(li_c, 0u);
         to_light = mk3(-l0.x, -l0.y, -l0.z);
+        if constexpr (kOneLight)
+        {
+          cone.axis = A.cone_axis;
+          cone.cos_m = A.cone_cos;
+          cone.sin_m = A.cone_sin;
+        }
+        else
+        {
+          f4 const l1 = env.light(li_c, 1u);
+          f4 const l2 = env.light(li_c, 2u);
+          cone.axis = mk3(l2.x, l2.y, l2.z);
+          cone.cos_m = l0.w;
+          cone.sin_m = l1.w;
+        }
       }
       if (deterministic)
       {
@@ -1300,7 +1380,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     float near_t;
     int near_i;
     RT_REGION(cnt, 9);
-    uint32_t const occluded = trace_pass<kGrid>(A, env, L.hp, dir, a, rays_on, near_t, near_i, cnt);
+    uint32_t const occluded = trace_pass<kGrid>(A, env, L.hp, dir, a, cone, rays_on, near_t, near_i, cnt);
 
     if (in_pass)
     {

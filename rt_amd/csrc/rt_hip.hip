@@ -19,7 +19,7 @@
 //
 //   camtab_kernel        per-launch set-up: table of the primary-ray filter (one entry per sphere), counters reset.
 //
-// LDS per block: the resident scene (48 B per sphere and material, 32 B per light) and 8 KB of prepared
+// LDS per block: the resident scene (48 B per sphere, material and light) and 8 KB of prepared
 // columns, or one 16 KB staging tile for scenes above kResidentSpheres spheres.
 #include "rt_core.h"
 #include "rt_hip.h"
@@ -252,7 +252,7 @@ struct WaveEnv
   const f4 * cam;        // LDS: n_padded camera-table records
   const f4 * exact;      // LDS: n_padded exact records
   const f4 * mats;       // LDS: 2 * n_materials
-  const f4 * lights;     // LDS: 2 * n_lights
+  const f4 * lights;     // LDS: RT_LIGHT_RECORDS * n_lights
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ColumnEntry * batch;   // LDS: this wave's kItemBatch prepared columns (column masks only)
   ItemPool pool;
@@ -266,7 +266,7 @@ struct WaveEnv
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[RT_MAT_RECORDS * m + k]; }
-  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return lights[2u * l + k]; }
+  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return lights[RT_LIGHT_RECORDS * l + k]; }
   __device__ __forceinline__ const float * jitter_table() const { return jitter; }
   __device__ __forceinline__ uint32_t tiles() const { return 1u; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
@@ -357,7 +357,7 @@ struct BlockEnv
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[RT_MAT_RECORDS * m + k]; }
-  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
+  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[RT_LIGHT_RECORDS * l + k]; }
   __device__ __forceinline__ const float * jitter_table() const { return jitter; }
   __device__ __forceinline__ uint32_t tiles() const { return (A.n_padded + A.tile_size - 1u) / A.tile_size; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t k) const { return k * A.tile_size; }
@@ -399,7 +399,7 @@ struct GridEnv
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return A.materials[RT_MAT_RECORDS * m + k]; }
-  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
+  __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return A.lights[RT_LIGHT_RECORDS * l + k]; }
   __device__ __forceinline__ const float * jitter_table() const { return jitter; }
   __device__ __forceinline__ uint32_t tiles() const { return 0u; }
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
@@ -427,7 +427,7 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
   unsigned long long const c1 = wave_sum(cnt.queries);
   unsigned long long const c2 = wave_sum(cnt.hits);
   unsigned long long const c3 = wave_sum(cnt.shaded);
-  unsigned long long const c4 = wave_sum(cnt.filter_tests) * A.n_spheres;
+  unsigned long long const c4 = wave_sum(cnt.filter_tests) * A.n_spheres + 5ull * wave_sum(cnt.cone_tests);
   unsigned long long const c5 = wave_sum(cnt.exact_tests);
   unsigned long long const c6 = wave_sum(cnt.trips);
   unsigned long long const c7 = wave_sum(cnt.rounds);
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     f4 * exact = cam + A.n_padded;
     f4 * mats = exact + A.n_padded;
     f4 * lights = mats + RT_MAT_RECORDS * A.n_materials;
-    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(lights + 2u * A.n_lights);
+    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(lights + RT_LIGHT_RECORDS * A.n_lights);
     for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
     {
       sph[i] = A.filter[i];
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     }
     for (uint32_t i = threadIdx.x; i < RT_MAT_RECORDS * A.n_materials; i += kBlock)
       mats[i] = A.materials[i];
-    for (uint32_t i = threadIdx.x; i < 2u * A.n_lights; i += kBlock)
+    for (uint32_t i = threadIdx.x; i < RT_LIGHT_RECORDS * A.n_lights; i += kBlock)
       lights[i] = A.lights[i];
     __syncthreads();
 #if defined(RT_PROFILE_REGIONS)
@@ -697,6 +697,7 @@ struct rt_hip_scene
   f4 * d_lights = nullptr;
   uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
   bool forward_ok = false;  // paths can be accumulated forward (rt_prep.h forward_accumulation_ok)
+  ShadowCone cone0;         // shadow cone of light 0 (kernels specialised for one light take it as an argument)
   // Blocks per compute unit of the trace kernel this scene is traced with, asked of the runtime once per kernel
   // variant ([1]: the grid walk) and LDS size rather than on every launch.
   struct Occupancy
@@ -753,6 +754,10 @@ uint32_t forced_tile()
   return std::min(std::max(n, 1u), kTileSpheres);
 }
 
+// RT_HIP_NO_CONES (any value): scenes created while it is set filter their shadow rays one by one against every
+// sphere instead of testing the cone that holds them first; for comparisons (same frames, same query counters).
+bool cones_disabled() { return std::getenv("RT_HIP_NO_CONES") != nullptr; }
+
 // RT_HIP_NO_SHARING (any value) switches sample sharing at the end of the queue off, for comparisons.
 bool share_disabled() { return std::getenv("RT_HIP_NO_SHARING") != nullptr; }
 
@@ -763,7 +768,7 @@ bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP
 size_t resident_lds_bytes(const rt_hip_scene * sc)
 {
   return (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS +
-         sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + 2u * sc->n_lights) +
+         sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + RT_LIGHT_RECORDS * sc->n_lights) +
          sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
 }
 
@@ -942,6 +947,9 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.tile_size = tile_size();
   a.n_materials = scene->n_materials;
   a.n_lights = scene->n_lights;
+  a.cone_axis = scene->cone0.axis;
+  a.cone_cos = scene->cone0.cos_m;
+  a.cone_sin = scene->cone0.sin_m;
   a.partial = d_partial;
   a.n_items = p->width * p->height * p->samples_in_row;
   a.stats = want_stats ? d_stats : nullptr;
@@ -1282,7 +1290,8 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
       return fail(RT_HIP_ERR_INVALID, "unknown light type");
 
   FlatScene fs;
-  flatten_scene(centers_radii, material_index, sphere_count, materials, material_count, lights, light_count, fs);
+  flatten_scene(centers_radii, material_index, sphere_count, materials, material_count, lights, light_count, fs,
+                !cones_disabled());
 
   rt_hip_scene * s = new (std::nothrow) rt_hip_scene;
   if (s == nullptr)
@@ -1291,6 +1300,7 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   s->n_padded = static_cast<uint32_t>(fs.spheres.size());
   s->n_materials = material_count;
   s->n_lights = light_count;
+  s->cone0 = shadow_cone(light_count ? lights[0].direction : nullptr, light_count != 0u && !cones_disabled());
   s->forward_ok = forward_accumulation_ok(materials, material_count) && std::getenv("RT_HIP_FORCE_STACK") == nullptr;
   auto upload = [](void ** dst, const void * src, size_t bytes) -> hipError_t {
     // Never a zero-byte allocation: keep the pointer valid for empty arrays.

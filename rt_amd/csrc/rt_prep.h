@@ -224,11 +224,38 @@ inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
 struct FlatScene
 {
   std::vector<f4> spheres;           // (cx, cy, cz, r*r)
-  std::vector<f4> filter;            // (cx, cy, cz, r*r widened by the filter margin)
+  std::vector<f4> filter;            // (cx, cy, cz, radius widened by the filter margin)
   std::vector<uint32_t> sphere_mat;  // material index per sphere
   std::vector<f4> materials;         // RT_MAT_RECORDS per material
-  std::vector<f4> lights;            // 2 per light
+  std::vector<f4> lights;            // RT_LIGHT_RECORDS per light
 };
+
+// The cone around the direction to a light that holds every shadow ray DirectionalLight::TraceLight can shoot
+// (ray_tracing/directional_light.cpp:20: normalize(-L + ballRand(0.25))); see ShadowCone in rt_core.h.  The
+// jitter vector is at most 0.25 long, so the rays stay within asin(0.25 / |L|) of -L; cos and sin of that angle
+// are moved to the safe side by a thousandth, which dwarfs the rounding of the kernel's float arithmetic.
+// use_cone = false (or a light shorter than about 0.28) gives the cone that holds every direction.
+inline ShadowCone shadow_cone(const float * light_direction, bool use_cone)
+{
+  ShadowCone c;
+  c.axis = mk3(0.0f, 1.0f, 0.0f);
+  c.cos_m = 0.0f;
+  c.sin_m = 3.0e38f;
+  if (light_direction == nullptr)
+    return c;
+  double const x = light_direction[0], y = light_direction[1], z = light_direction[2];
+  double const len = std::sqrt(x * x + y * y + z * z);
+  if (!(len > 1e-20) || !std::isfinite(len))
+    return c;
+  c.axis = mk3((float)(-x / len), (float)(-y / len), (float)(-z / len));
+  double const sin_t = 0.25 * (1.0 + 1e-5) / len;
+  if (!use_cone || !(sin_t < 0.9))
+    return c;
+  double const sin_m = sin_t * 1.001 + 1e-4;
+  c.sin_m = (float)sin_m;
+  c.cos_m = (float)(std::sqrt(1.0 - sin_m * sin_m) * 0.999);
+  return c;
+}
 
 RT_HD f4 mk4(float x, float y, float z, float w)
 {
@@ -240,9 +267,11 @@ RT_HD f4 mk4(float x, float y, float z, float w)
   return r;
 }
 
+// shadow_cones = false: every light gets the cone that holds all directions, so the shadow rays are filtered one
+// by one against every sphere (for comparisons; same frames).
 inline void flatten_scene(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                           const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
-                          FlatScene & out)
+                          FlatScene & out, bool shadow_cones = true)
 {
   out.spheres.resize(n);
   out.filter.resize(n);
@@ -252,8 +281,9 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
     const float * s = centers_radii + 4u * i;
     float const r2 = s[3] * s[3];  // m_radius * m_radius, sphere.cpp:68
     out.spheres[i] = mk4(s[0], s[1], s[2], r2);
-    double const widened = static_cast<double>(r2) * (1.0 + RT_FILTER_MARGIN);
-    out.filter[i] = mk4(s[0], s[1], s[2], std::nextafter(static_cast<float>(widened), INFINITY));
+    // the widened radius: its float square is at least r^2 (1 + m) whatever way the product rounds
+    double const widened = std::fabs(static_cast<double>(s[3])) * (1.0 + RT_FILTER_MARGIN);
+    out.filter[i] = mk4(s[0], s[1], s[2], std::max(std::nextafter(static_cast<float>(widened), INFINITY), 1e-30f));
   }
   // Per-material constants of Scatter and GetSpecular, computed here once with the float operations the
   // reference uses per hit (ray_tracing/default_materials.cpp:30,50,61-62; directional_light.cpp:49-56).
@@ -274,11 +304,13 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
     out.materials[RT_MAT_RECORDS * i + 1u] = mk4(refraction, type_bits, f2, inv_refraction);
     out.materials[RT_MAT_RECORDS * i + 2u] = mk4(r2, 4.0f * r2, e_metal, 0.0f);
   }
-  out.lights.resize(2u * l);
+  out.lights.resize((size_t)RT_LIGHT_RECORDS * l);
   for (uint32_t i = 0; i < l; ++i)
   {
-    out.lights[2u * i] = mk4(lights[i].direction[0], lights[i].direction[1], lights[i].direction[2], 0.0f);
-    out.lights[2u * i + 1u] = mk4(lights[i].color[0], lights[i].color[1], lights[i].color[2], 0.0f);
+    ShadowCone const cone = shadow_cone(lights[i].direction, shadow_cones);
+    out.lights[RT_LIGHT_RECORDS * i] = mk4(lights[i].direction[0], lights[i].direction[1], lights[i].direction[2], cone.cos_m);
+    out.lights[RT_LIGHT_RECORDS * i + 1u] = mk4(lights[i].color[0], lights[i].color[1], lights[i].color[2], cone.sin_m);
+    out.lights[RT_LIGHT_RECORDS * i + 2u] = mk4(cone.axis.x, cone.axis.y, cone.axis.z, 0.0f);
   }
 }
 }  // namespace rtc

@@ -84,7 +84,7 @@ struct HostEnv
   rtc::f4 sphere(int i) const { return A.spheres[i]; }
   uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
   rtc::f4 material(uint32_t m, uint32_t k) const { return A.materials[rtc::RT_MAT_RECORDS * m + k]; }
-  rtc::f4 light(uint32_t l, uint32_t k) const { return A.lights[2u * l + k]; }
+  rtc::f4 light(uint32_t l, uint32_t k) const { return A.lights[rtc::RT_LIGHT_RECORDS * l + k]; }
   const float * jitter_table() const { return A.jitter_tab; }
   uint32_t tiles() const { return (A.n_padded + tile_size - 1) / tile_size; }
   uint32_t tile_base(uint32_t k) const { return k * tile_size; }
@@ -102,7 +102,7 @@ struct HostEnv
 // tile_size: records per staged tile (exercises the multi-tile path when smaller than the scene).
 // mode: bit 0 = column masks (scenes of at most 64 spheres, one tile), bit 1 = forward accumulation,
 // bit 2 = rays walk the uniform grid, bit 3 = sample-sharing test mode (see HostEnv), bit 4 = the general loop
-// even for a scene with one light.
+// even for a scene with one light, bit 5 = no shadow cones (shadow rays filtered one by one).
 extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * material_index, uint32_t n,
                                const rt_hip_material * mats, uint32_t m, const rt_hip_light * lights, uint32_t l,
                                const rt_hip_camera * cam, const rt_hip_trace_params * p, uint32_t tile_size,
@@ -131,9 +131,15 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
                                uint32_t mode, float * rgb, unsigned long long * stats6)
 {
   rtc::FlatScene fs;
-  rtc::flatten_scene(centers_radii, material_index, n, mats, m, lights, l, fs);
+  rtc::flatten_scene(centers_radii, material_index, n, mats, m, lights, l, fs, (mode & 32u) == 0u);
   rtc::TraceArgs a{};
   rtc::prepare_frame(*cam, *p, a);
+  if (l != 0u)
+  {
+    a.cone_axis = rtc::mk3(fs.lights[2].x, fs.lights[2].y, fs.lights[2].z);
+    a.cone_cos = fs.lights[0].w;
+    a.cone_sin = fs.lights[1].w;
+  }
   uint32_t const padded = static_cast<uint32_t>(fs.filter.size());
   bool const column_masks = (mode & 1u) != 0u && padded > 0 && padded <= 64;
   a.column_masks = column_masks ? 1u : 0u;
@@ -232,7 +238,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     stats6[1] = cnt.queries;
     stats6[2] = cnt.hits;
     stats6[3] = cnt.shaded;
-    stats6[4] = (unsigned long long)cnt.filter_tests * n;
+    stats6[4] = (unsigned long long)cnt.filter_tests * n + 5ull * cnt.cone_tests;
     stats6[5] = cnt.exact_tests;
   }
   return 0;

@@ -196,16 +196,36 @@ def test_full_size_frame_properties(hip, ffi, scenes):
     np.testing.assert_array_equal(a, b)  # no atomics on pixels: bitwise reproducible
     assert sa.samples == 1920 * 1080 * 256
     assert sa.samples + 5 * sa.shaded_bounces <= sa.ray_queries <= sa.samples + 6 * sa.shaded_bounces
-    # executed filter tests: every shadow and scattered ray against every sphere, primary rays once per column
-    # (a path's last scattered ray is traced with the shadow rays but only counted as a query below the depth limit)
-    secondary = sa.ray_queries - sa.samples
+    # executed filter tests: per shaded bounce the shadow cone and the scattered ray against every sphere, primary
+    # rays once per column, and five shadow rays against each sphere a cone touched (few)
     columns = 1920 * 1080 * 16
-    assert (secondary + columns) * scene.sphere_count <= sa.sphere_tests
-    assert sa.sphere_tests <= (6 * sa.shaded_bounces + columns) * scene.sphere_count
+    per_sphere = (2 * sa.shaded_bounces + columns) * scene.sphere_count
+    assert per_sphere <= sa.sphere_tests <= 1.25 * per_sphere
     np.testing.assert_allclose(a[0, :, :], 0.9, rtol=1e-6)  # the top row sees only sky
     assert np.isfinite(a).all() and a.min() >= 0.0
     # the low-resolution oracle render of the same view has the same mean radiance
     assert abs(float(a.mean()) - 0.746) < 0.01
+
+
+@pytest.mark.parametrize("demo,spheres,size", [(1, 0, (640, 360, 4)), (2, 0, (320, 180, 6)), (3, 600, (160, 90, 2))],
+                         ids=["pretty", "glass", "field600"])
+def test_shadow_cones_change_no_bit(hip, ffi, demo, spheres, size, monkeypatch):
+    """The five shadow rays of a light are filtered as one cone first; scenes created under RT_HIP_NO_CONES filter
+    them one by one against every sphere.  Same frame, same query counters, far fewer filter tests."""
+    w, h, s = size
+    with_cones = ffi.Scene.demo(demo, 1, spheres)
+    monkeypatch.setenv("RT_HIP_NO_CONES", "1")
+    without = ffi.Scene.demo(demo, 1, spheres)
+    hip.upload(without)
+    monkeypatch.delenv("RT_HIP_NO_CONES")
+    for flags, seed in ((ffi.FLAG_DETERMINISTIC, 1), (0, 5)):
+        p = ffi.params(w, h, s, flags=flags, seed=seed)
+        a, sa = hip.render(with_cones, p)
+        b, sb = hip.render(without, p)
+        np.testing.assert_array_equal(a, b)
+        assert (sa.samples, sa.ray_queries, sa.hit_queries, sa.shaded_bounces, sa.exact_tests) == \
+               (sb.samples, sb.ray_queries, sb.hit_queries, sb.shaded_bounces, sb.exact_tests)
+        assert sa.sphere_tests < 0.6 * sb.sphere_tests
 
 
 @pytest.mark.parametrize("spheres", [300, 3000])
@@ -220,7 +240,7 @@ def test_grid_walk_equals_testing_every_sphere(hip, oracle, ffi, scenes, spheres
         np.testing.assert_array_equal(grid, brute)
         assert (sg.samples, sg.ray_queries, sg.hit_queries, sg.shaded_bounces) == \
                (sb.samples, sb.ray_queries, sb.hit_queries, sb.shaded_bounces)
-        assert sg.sphere_tests == 0 and sg.exact_tests < 0.05 * sb.sphere_tests
+        assert sg.sphere_tests == 0 and sg.exact_tests < 0.15 * sb.sphere_tests
     p = ffi.params(96, 72, 2, flags=ffi.FLAG_DETERMINISTIC | ffi.FLAG_GRID)
     ref, rs = oracle.render(scene, ffi.params(96, 72, 2, flags=ffi.FLAG_DETERMINISTIC))
     out, st = hip.render(scene, p)
