@@ -36,10 +36,13 @@ rt_amd/lib_prof/librt_hip.so: rt_amd/csrc/rt_hip.hip $(CORE_HDRS)
 	@mkdir -p rt_amd/lib_prof
 	$(HIPCC) $(HIPFLAGS) -DRT_PROFILE_REGIONS -shared rt_amd/csrc/rt_hip.hip -o $@
 
-checkers: oracle/librt_oracle.so oracle/liboracle_frame.so tests/emu/libcore_emu.so
+checkers: oracle/librt_oracle.so oracle/librt_oracle_o3.so oracle/liboracle_frame.so tests/emu/libcore_emu.so
 
 oracle/librt_oracle.so: oracle/rt_oracle.c oracle/rt_oracle.h
 	$(MAKE) -C oracle librt_oracle.so
+
+oracle/librt_oracle_o3.so: oracle/rt_oracle.c oracle/rt_oracle.h
+	$(MAKE) -C oracle librt_oracle_o3.so
 
 oracle/liboracle_frame.so: oracle/frame_cpu.cpp oracle/librt_oracle.so $(HOST_HDRS)
 	$(MAKE) -C oracle liboracle_frame.so

@@ -13,9 +13,18 @@ the timed region, so the value is the throughput of a stream of frames, not the 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints one JSON line.  `roofline` prices the trace kernel's algorithmic FLOPs (20 per ray-sphere test,
-30 per hit, 250 per shaded bounce; counted on the device) against the FP32 vector peak, with the kernel's
-duration measured by HIP events on its launch stream; `cpu_baseline` times the CPU restatement of the
+Rank 0 prints one JSON line.  `value` / `ms_per_step` are the throughput of that stream of frames (two in flight),
+images left on the device; beside them the line carries the latency of a frame traced alone
+(`ms_per_frame_one_at_a_time`), the same with the download of the image into pinned host memory
+(`ms_per_frame_one_at_a_time_with_d2h`) and, on one GPU, the period of a stream of frames through the job API
+with every image downloaded while the next frame is traced (`ms_per_frame_with_d2h`).
+
+`roofline` prices the trace kernel's algorithmic FLOPs (20 per ray-sphere test, 30 per hit, 250 per shaded
+bounce; counted on the device) against the FP32 vector peak, with the kernel's duration measured by HIP events on
+its launch stream.  That credit is a property of the algorithm, not of the instructions run: the filter spends
+far fewer than 20 FLOP per test, so `roofline.executed` also prices the vector instructions the kernel actually
+issued (modelled from the device counters, or SQ_INSTS_VALU when a counter profile of the workload is committed)
+against the issue peak, a fraction that cannot exceed 1.  `cpu_baseline` times the CPU restatement of the
 reference's multithreaded path on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
@@ -32,21 +41,49 @@ sys.path.insert(0, ROOT)
 from rt_amd import ffi, sharding  # noqa: E402
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X: 256 CUs x 4 SIMDs x 32 lanes x 2 FLOP x 2.4 GHz
+PEAK_VALU_LANE_OPS = 78.64e12    # ... of which one vector instruction per lane and clock: 256 x 4 x 32 x 2.4 GHz
+
+# Vector instructions per unit of work, counted in the kernel's ISA (tools/isa_regions.py): what the executed-work
+# model multiplies the device counters with.
+INSTR_SHADE_SPHERE = 20    # one sphere in a shade pass: offset, bound, shadow cone test, scattered-ray test
+INSTR_PRIMARY_TEST = 4     # one camera-table entry against one direction (3 FMA + the mask shift)
+INSTR_CONE_SPHERE = 45     # one sphere the cone touched against the five shadow rays
+INSTR_EXACT_TEST = 45      # one exact intersection (IEEE square root and division expanded)
+INSTR_SHADED_BOUNCE = 1050 # scatter, specular, two Philox blocks, six ray set-ups, light sum, path bookkeeping
+INSTR_SAMPLE = 160         # primary direction, item bookkeeping, hit set-up, share of column preparation
 
 
 def algorithmic_flop(stats, n_spheres):
     return 20.0 * n_spheres * stats["ray_queries"] + 30.0 * stats["hit_queries"] + 250.0 * stats["shaded_bounces"]
 
 
-def profiled_traffic(workload_key):
-    """HBM bytes per trace launch from the committed rocprofv3 counter passes (FETCH_SIZE doubled as the gfx950
-    guide prescribes for wide reads, plus WRITE_SIZE), or None when this workload was not profiled."""
+def executed_lane_ops(stats, n_spheres, grid, column_masks):
+    """Vector instructions x lanes the trace kernel issued for these counters (see INSTR_*); None for grid walks,
+    whose work is not in the counters.  A wave issues for all its lanes, busy or idle, so the passes over the
+    scene are counted per loop trip of a lane (lane_trips: one shade pass each; lane_rounds: one primary filter
+    pass each where primary rays are filtered per sample)."""
+    if grid:
+        return None
+    shade = stats["lane_trips"] * n_spheres
+    if column_masks:
+        primary = max(stats["sphere_tests"] - 2 * stats["shaded_bounces"] * n_spheres, 0)  # once per column
+    else:
+        primary = stats["lane_rounds"] * n_spheres
+    return (INSTR_SHADE_SPHERE * shade + INSTR_PRIMARY_TEST * primary + INSTR_CONE_SPHERE * stats["cone_tests"] +
+            INSTR_EXACT_TEST * stats["exact_tests"] + INSTR_SHADED_BOUNCE * stats["lane_trips"] +
+            INSTR_SAMPLE * stats["lane_rounds"])
+
+
+def profiled(workload_key):
+    """What the committed rocprofv3 counter passes hold for this workload (profiles/traffic.json): HBM bytes per
+    trace launch (FETCH_SIZE doubled as the gfx950 guide prescribes for wide reads, plus WRITE_SIZE) and the
+    vector instruction count; {} when the workload was not profiled."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload_key, {}).get("trace_kernel_bytes_per_launch")
+            return json.load(f).get(workload_key, {})
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def cpu_model():
@@ -74,13 +111,23 @@ def cpu_baseline(scene, width, height, samples_in_row):
     t0 = time.perf_counter()
     _, st1 = oracle_ffi.render(scene, p1, 1)
     dt1 = time.perf_counter() - t0
+    # the same sample with the oracle built -O3 -march=x86-64-v3 (still no FMA contraction: same frames)
+    o3 = None
+    try:
+        t0 = time.perf_counter()
+        _, st3 = oracle_ffi.render(scene, p, threads, build="o3")
+        o3 = round(st3.samples / (time.perf_counter() - t0) / 1e6, 3)
+    except OSError:
+        pass
     return {
         "value": round(st.samples / dt / 1e6, 3),
         "unit": "Msamples/s",
         "cores": threads,
         "kind": "port",
+        "compiler_flags": "-O2 -ffp-contract=off",
         "sample": "same scene and camera at %dx%d, %dx%d samples per pixel (%.1f Msamples, %.1f s)"
                   % (width, height, samples_in_row, samples_in_row, st.samples / 1e6, dt),
+        "value_o3_x86_64_v3": o3,
         "value_1_thread": round(st1.samples / dt1 / 1e6, 3),
         "sample_1_thread": "%dx%d, %dx%d samples per pixel (%.1f Msamples, %.1f s)"
                            % (p1.width, p1.height, samples_in_row, samples_in_row, st1.samples / 1e6, dt1),
@@ -103,6 +150,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-reduce", action="store_true",
                     help="one frame at a time on one stream (default: two frames in flight on two streams)")
+    ap.add_argument("--no-room", action="store_true",
+                    help="several GPUs: do not leave block slots free for the RCCL reduce kernel")
     ap.add_argument("--rehearse", action="store_true",
                     help="rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
                          "collectives run over gloo on host copies (timings are not meaningful)")
@@ -140,6 +189,11 @@ def main():
     if scene.sphere_count > 64 and not args.grid:
         args.sync_reduce = True
     flags = (ffi.FLAG_GRID if args.grid else 0) | (0 if args.sync_reduce else ffi.FLAG_PIPELINED)
+    # With a reduce to overlap, the trace leaves 64 of the chip's 1024 block slots free: the RCCL kernel that sums
+    # frame k would otherwise find every compute unit taken by the trace of frame k + 1.  One GPU has no reduce
+    # and uses every slot.
+    if distributed and not args.rehearse and not args.no_room:
+        flags |= ffi.FLAG_LEAVE_ROOM
     p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world)
     full = ffi.params(w, h, s, seed=1, flags=flags)
 
@@ -207,37 +261,75 @@ def main():
         elapsed = float(t.item())
 
     # The same frame one at a time (no overlap of frames, no flag that announces one): what a caller that needs
-    # each image before it asks for the next would see.  Reported beside the headline, never as it.
+    # each image before it asks for the next would see.  Reported beside the headline, never as it.  Measured twice:
+    # image left on the device, and downloaded into pinned host memory (rank 0; the whole-job metric with PCIe).
     p_alone = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED), rank, world)
     singles = max(2, min(args.steps, 5))
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(singles):
-        stream = torch.cuda.current_stream().cuda_stream
-        renderer.trace_device(scene, p_alone, planes[0].data_ptr(), d_stats[1].data_ptr(), stream)
-        if rehearsing:
-            host[0].copy_(planes[0])
-            sharding.reduce_to_root(dist, host[0], world)
-            planes[0].copy_(host[0])
-        else:
-            sharding.reduce_to_root(dist, planes[0], world)
-        if rank == 0:
-            renderer.resolve_device(planes[0].data_ptr(), rgbs[1].data_ptr(), full, stream)
-    fence()
-    single_ms = (time.perf_counter() - t1) / singles * 1e3
-    if distributed:
-        t = torch.tensor([single_ms], dtype=torch.float64, device="cpu" if args.rehearse else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        single_ms = float(t.item())
+    pinned = torch.empty(w * h * 3, dtype=torch.float32, pin_memory=True) if rank == 0 else None
+
+    def frames_alone(download):
+        fence()
+        t = time.perf_counter()
+        for _ in range(singles):
+            stream = torch.cuda.current_stream().cuda_stream
+            renderer.trace_device(scene, p_alone, planes[0].data_ptr(), d_stats[1].data_ptr(), stream)
+            if rehearsing:
+                host[0].copy_(planes[0])
+                sharding.reduce_to_root(dist, host[0], world)
+                planes[0].copy_(host[0])
+            else:
+                sharding.reduce_to_root(dist, planes[0], world)
+            if rank == 0:
+                renderer.resolve_device(planes[0].data_ptr(), rgbs[1].data_ptr(), full, stream)
+                if download:
+                    pinned.copy_(rgbs[1], non_blocking=True)
+                    torch.cuda.current_stream().synchronize()  # the caller has the image before the next frame
+        fence()
+        ms = (time.perf_counter() - t) / singles * 1e3
+        if distributed:
+            tt = torch.tensor([ms], dtype=torch.float64, device="cpu" if args.rehearse else device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt.item())
+        return ms
+
+    single_ms = frames_alone(False)
+    single_d2h_ms = frames_alone(True)
+
+    # One GPU: a stream of whole frames through the job API, every image downloaded (pinned host memory) on the
+    # library's copy stream while the next frame is being traced -- the PCIe-inclusive period of a frame.
+    stream_d2h_ms = None
+    if not distributed:
+        import numpy as np
+
+        frames = max(3, min(args.steps, 8))
+        host_images = [torch.empty(w * h * 3, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        p_job = ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED)
+
+        def finish_into(job, k):
+            rc = renderer.lib.rt_hip_job_finish(job, host_images[k % 2].data_ptr(), None)
+            if rc != 0:
+                raise ffi.HipError("rt_hip_job_finish failed (%d): %s" % (rc, renderer.lib.rt_hip_last_error().decode()))
+
+        fence()
+        finish_into(renderer.start(scene, p_job), 0)  # buffers of the job path exist from here on
+        finish_into(renderer.start(scene, p_job), 1)
+        t = time.perf_counter()
+        job = renderer.start(scene, p_job)
+        for k in range(frames):
+            nxt = renderer.start(scene, p_job) if k + 1 < frames else None
+            finish_into(job, k)
+            job = nxt
+        stream_d2h_ms = (time.perf_counter() - t) / frames * 1e3
+        del np
 
     # counters of this rank's last trace, summed over ranks
-    counters = d_stats[0][:8].clone()
+    counters = d_stats[0][:9].clone()
     if distributed:
         if args.rehearse:
             counters = counters.cpu()
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     names = ["samples", "ray_queries", "hit_queries", "shaded_bounces", "sphere_tests", "exact_tests", "lane_trips",
-             "lane_rounds"]
+             "lane_rounds", "cone_tests"]
     stats = dict(zip(names, (int(x) for x in counters.tolist())))
 
     # roofline of the dominant kernel: this rank's trace kernel, HIP events on its launch stream
@@ -264,6 +356,46 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         total_samples = w * h * s * s
         mean_radiance = float(rgbs[0].mean().item())
+        demo_name = {1: "pretty_spheres", 2: "glass_spheres", 3: "synthetic_spheres"}[args.demo]
+        key = "demo%d_%dx%d_s%d_g%d" % (args.demo, w, h, s, world) + ("_n%d" % args.spheres if args.demo == 3 else "") + \
+              ("_grid" if args.grid else "")
+        prof = profiled(key)
+        traffic = prof.get("trace_kernel_bytes_per_launch")
+        column_bytes = 12 * w * h * s  # what the algorithm writes to HBM: one column sum per sub-sample column
+        # vector instructions the kernel issued: counted by SQ_INSTS_VALU (64 lanes each) when this workload has a
+        # committed counter profile, else modelled from this run's device counters
+        lane_ops = executed_lane_ops(k, scene.sphere_count, args.grid, scene.sphere_count <= 64)
+        executed = None
+        if prof.get("valu_wave_instructions"):
+            executed = {"valu_lane_ops": 64.0 * prof["valu_wave_instructions"], "source": prof.get("source")}
+        elif lane_ops is not None:
+            executed = {"valu_lane_ops": float(lane_ops), "source": "model: device counters x instructions per unit"}
+        if executed is not None:
+            rate = executed["valu_lane_ops"] / (kernel_ms * 1e-3)
+            executed.update({
+                "modelled_valu_lane_ops": float(lane_ops) if lane_ops is not None else None,
+                "achieved": round(rate / 1e12, 2),
+                "peak": round(PEAK_VALU_LANE_OPS / 1e12, 2),
+                "unit": "T lane-instructions/s",
+                "frac": round(rate / PEAK_VALU_LANE_OPS, 4),
+                "note": "vector instructions x 64 lanes over the kernel time, against one instruction per lane and "
+                        "clock (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz); cannot exceed 1, unlike the algorithmic "
+                        "credit of 20 FLOP per test, which the filter undercuts",
+            })
+        if args.grid:
+            bound = "latency (grid walk; achieved/frac credit the brute-force test count and do not apply)"
+        else:
+            bound = "valu_fp32"
+        hbm_bytes = traffic if traffic is not None else column_bytes
+        bound_note = ("FP32 vector-ALU issue, neither HBM nor MFMA: %.3f GB of HBM traffic (%s) per launch of %.3g FLOP "
+                      "is %.0f FLOP per byte and %.1f GB/s, no matrix work"
+                      % (hbm_bytes / 1e9, "PMC counters" if traffic is not None else "algorithmic column sums",
+                         kernel_flop, kernel_flop / max(hbm_bytes, 1), hbm_bytes / (kernel_ms * 1e-3) / 1e9))
+        collective = {"backend": None, "world_size": 1}
+        if distributed:
+            collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                          "op": "reduce(SUM, dst=0) of 3*W*H float32 per frame",
+                          "trace_leaves_room_for_it": bool(flags & ffi.FLAG_LEAVE_ROOM)}
         out = {
             "metric": "Msamples/s (camera samples, each traced to its end: primary, scattered and shadow rays)",
             "value": round(total_samples / (elapsed / args.steps) / 1e6, 2),
@@ -279,36 +411,44 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s %dx%d, %dx%d SSAA, %d spheres, samples sharded over %d GPU(s), RCCL sum-reduce"
-                            % ({1: "pretty_spheres", 2: "glass_spheres", 3: "synthetic_spheres"}[args.demo], w, h, s, s,
-                               scene.sphere_count, world),
+                            % (demo_name, w, h, s, s, scene.sphere_count, world),
                 "scene_seed": 1,
                 "render_seed": 1,
                 "max_depth": 10,
                 "intersection": "uniform grid" if args.grid else "every sphere (LDS-resident or LDS-tiled)",
                 "frames_in_flight": lanes,
+                "collective": collective,
             },
+            "value_note": "throughput of a stream of frames, %d in flight, images left in HBM; the latency of one frame "
+                          "is ms_per_frame_one_at_a_time" % lanes,
             "ms_per_frame_one_at_a_time": round(single_ms, 3),
+            "ms_per_frame_one_at_a_time_with_d2h": round(single_d2h_ms, 3),
+            "ms_per_frame_with_d2h": round(stream_d2h_ms, 3) if stream_d2h_ms is not None else None,
             "mrays_per_s": round(stats["ray_queries"] / (elapsed / args.steps) / 1e6, 1),
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),
             "mean_radiance": round(mean_radiance, 5),
             "roofline": {
-                "bound": "valu_fp32" if not args.grid else "latency (grid walk; achieved/frac below still credit "
-                                                          "the brute-force test count and do not apply)",
-                "bound_note": "FP32 vector-ALU issue; this kernel is neither HBM- nor MFMA-bound "
-                              "(0.43 GB of HBM traffic per 3.2 TFLOP launch, no matrix work)",
+                "bound": bound,
+                "bound_note": bound_note,
                 "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
-                "traffic": profiled_traffic("demo%d_%dx%d_s%d_g%d" % (args.demo, w, h, s, world)),
+                "traffic": traffic,
+                "traffic_source": prof.get("source") if traffic is not None else None,
+                "algorithmic_hbm_bytes": column_bytes,
                 "kernel": "trace_kernel",
                 "kernel_ms": round(kernel_ms, 3),
                 "flop_per_launch": kernel_flop,
+                "executed": executed,
                 "executed_filter_tests": k["sphere_tests"],
+                "executed_cone_tests": k["cone_tests"],
                 "executed_exact_tests": k["exact_tests"],
                 "executed_over_algorithmic_tests": round(
                     k["sphere_tests"] / max(k["ray_queries"] * scene.sphere_count, 1), 4),
-                "lane_utilisation": round(k["shaded_bounces"] / max(k["lane_trips"], 1), 4),
+                "lane_trips": k["lane_trips"],
+                "lane_rounds": k["lane_rounds"],
+                "shading_trip_share": round(k["shaded_bounces"] / max(k["lane_trips"], 1), 4),
             },
         }
         out["resolve_pass"] = {

@@ -64,6 +64,10 @@ extern "C" {
                                         end leaves idle, so the launch keeps its work reservations large to the end
                                         instead of shrinking them to finish early.  Same image. */
 
+#define RT_HIP_FLAG_LEAVE_ROOM 8u    /* the launch leaves 64 of the chip's block slots (of 1024) free, so that another
+                                        kernel -- the RCCL reduce of the previous frame on a multi-GPU driver -- finds
+                                        compute units while this frame is traced.  Same image. */
+
 /* Replaces CudaMaterial (rt_cuda/types_cuda.h): what Material::GetType/GetAlbedo/GetRoughness/
  * GetRefraction return (ray_tracing/material.hpp:20-26). */
 typedef struct
@@ -114,12 +118,13 @@ typedef struct
   uint64_t ray_queries;    /* nearest-hit + shadow queries the algorithm asks for, each against all spheres */
   uint64_t hit_queries;    /* queries that found a hit */
   uint64_t shaded_bounces; /* hits that ran direct light + specular */
-  uint64_t sphere_tests;   /* ray-sphere filter tests executed: every shadow and scattered ray against every sphere;
-                              primary rays once per sample, or once per column for scenes of at most 64 spheres;
-                              0 on the grid path */
+  uint64_t sphere_tests;   /* filter tests executed against every sphere of the scene: per shaded bounce the cone that
+                              holds the light's five shadow rays and the scattered ray; primary rays once per sample,
+                              or once per column for scenes of at most 64 spheres; 0 on the grid path */
   uint64_t exact_tests;    /* exact intersections run: the candidates the filter (or the grid walk) let through */
   uint64_t lane_trips;     /* trips round the kernel's main loop, summed over lanes (busy or idle) */
   uint64_t lane_rounds;    /* primary-ray rounds inside those trips, summed over lanes (busy or idle) */
+  uint64_t cone_tests;     /* spheres a shadow cone touched; each was then tested against the five shadow rays */
   float kernel_ms;         /* device time of the trace kernel, HIP events on the launch stream; 0 if not measured */
   uint32_t reserved;
 } rt_hip_stats;
@@ -177,7 +182,7 @@ int rt_hip_job_cancel(rt_hip_job * job);
 /* Device-resident form of the same frame, for callers that own device memory and a stream (multi-GPU
  * drivers, benchmarks): traces the requested slice into d_sum_planes (float[3*h*w], device memory, fully
  * overwritten) on `stream` (a hipStream_t passed as void*; NULL = the default stream), asynchronously.
- * d_stats (device memory, 128 bytes, may be NULL) receives the eight uint64 counters of rt_hip_stats for
+ * d_stats (device memory, 128 bytes, may be NULL) receives the nine uint64 counters of rt_hip_stats for
  * this call, in declaration order (the kernel also keeps its queue word there, so calls in flight at the same
  * time need different buffers).  Calls on one stream run in order; calls on different streams may overlap --
  * the library keeps a grow-only workspace per stream, eight of them (a ninth stream takes over the least

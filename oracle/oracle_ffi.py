@@ -121,9 +121,26 @@ def orc_scene(scene):
     return s
 
 
-def render(scene, p, threads=None):
-    """Whole frame on the CPU; returns (rgb[h,w,3] float32, OrcStats)."""
-    lib = load()
+_O3_PATH = os.path.join(_HERE, "librt_oracle_o3.so")
+_o3 = None
+
+
+def load_o3():
+    """The same source built -O3 -march=x86-64-v3 (no FMA contraction either): only for timing the CPU baseline
+    with the optimiser let loose; its frames equal the -O2 build's.  OSError if it was not built."""
+    global _o3
+    if _o3 is None:
+        lib = C.CDLL(_O3_PATH)
+        lib.orc_render.restype = C.c_int
+        lib.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32,
+                                   C.c_void_p, C.POINTER(OrcStats)]
+        _o3 = lib
+    return _o3
+
+
+def render(scene, p, threads=None, build=None):
+    """Whole frame on the CPU; returns (rgb[h,w,3] float32, OrcStats).  build="o3": the -O3 build (timing only)."""
+    lib = load_o3() if build == "o3" else load()
     if threads is None:
         threads = min(os.cpu_count() or 1, 16)
     rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)

@@ -40,6 +40,16 @@ namespace
 {
 using namespace rtc;
 
+// Tuning knobs an experiment build may override (-D...); the values here are the measured best.
+#ifndef RT_WAVE_UNROLL
+#define RT_WAVE_UNROLL 2
+#endif
+#ifndef RT_BLOCK_UNROLL
+#define RT_BLOCK_UNROLL 4
+#endif
+#ifndef RT_TILED_WAVES
+#define RT_TILED_WAVES 4
+#endif
 constexpr int kBlock = 256;               // 4 waves
 constexpr int kWavesPerSimd = 3;          // blocks per CU the register budget is sized for (path stacks in LDS)
 // Without the stacks four waves per SIMD fit, 128 registers each (7 % faster than three).  That fills the
@@ -58,7 +68,7 @@ constexpr uint32_t kColumnMaskSpheres = 64;   // column masks: two 32-bit words 
 constexpr uint32_t kGridMinSpheres = 64;      // smaller scenes get no grid: testing every sphere is faster
 constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS whole (48 B per sphere)
 constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
-constexpr uint32_t kStatsWords = 8;
+constexpr uint32_t kStatsWords = 9;
 
 // ---- rt_hip_trace_device_static: the one entry point that allocates nothing ----
 // Its scratch (counters, camera table, column sums, sample-sharing room) is this file-scope array instead of a
@@ -246,7 +256,7 @@ __device__ __forceinline__ void append_split(const TraceArgs & A, uint32_t slot,
 // The whole scene is resident in LDS; waves never wait for each other.
 struct WaveEnv
 {
-  static constexpr uint32_t kFilterUnroll = 2;
+  static constexpr uint32_t kFilterUnroll = RT_WAVE_UNROLL;
   const TraceArgs & A;
   const f4 * filt;       // LDS: n_padded filter records
   const f4 * cam;        // LDS: n_padded camera-table records
@@ -336,7 +346,7 @@ struct WaveEnv
 // pass, so all of its waves take the same trips and every loop decision is block-wide.
 struct BlockEnv
 {
-  static constexpr uint32_t kFilterUnroll = 4;  // almost all of this path's time is the filter: three waves, wider loop
+  static constexpr uint32_t kFilterUnroll = RT_BLOCK_UNROLL;  // almost all of this path's time is the filter
   const TraceArgs & A;
   f4 * tile;              // LDS: kTileSpheres entries
   const float * jitter;   // LDS: RT_JITTER_FLOATS
@@ -427,7 +437,8 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
   unsigned long long const c1 = wave_sum(cnt.queries);
   unsigned long long const c2 = wave_sum(cnt.hits);
   unsigned long long const c3 = wave_sum(cnt.shaded);
-  unsigned long long const c4 = wave_sum(cnt.filter_tests) * A.n_spheres + 5ull * wave_sum(cnt.cone_tests);
+  unsigned long long const c4 = wave_sum(cnt.filter_tests) * A.n_spheres;
+  unsigned long long const c8 = wave_sum(cnt.cone_tests);
   unsigned long long const c5 = wave_sum(cnt.exact_tests);
   unsigned long long const c6 = wave_sum(cnt.trips);
   unsigned long long const c7 = wave_sum(cnt.rounds);
@@ -441,6 +452,7 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
     atomicAdd(&A.stats[5], c5);
     atomicAdd(&A.stats[6], c6);
     atomicAdd(&A.stats[7], c7);
+    atomicAdd(&A.stats[8], c8);
   }
 #if defined(RT_PROFILE_REGIONS)
   RT_REGION(cnt, 4);
@@ -453,7 +465,7 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
 template <bool kTiled, bool kForward, bool kOneLight>
-__global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel(TraceArgs A)
+__global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : (kTiled && kForward ? RT_TILED_WAVES : kWavesPerSimd)) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   f4 * stack = reinterpret_cast<f4 *>(lds_raw);                    // [RT_MAX_DEPTH][kBlock]
@@ -812,7 +824,11 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
     return one ? go(trace_kernel_grid<true, true>) : go(trace_kernel_grid<true, false>);
   }
   if (is_tiled(sc))
-    return sc->forward_ok ? go(trace_kernel<true, true, false>) : go(trace_kernel<true, false, false>);
+  {
+    if (!sc->forward_ok)
+      return go(trace_kernel<true, false, false>);
+    return one ? go(trace_kernel<true, true, true>) : go(trace_kernel<true, true, false>);
+  }
   if (!sc->forward_ok)
     return go(trace_kernel<false, false, false>);
   return one ? go(trace_kernel<false, true, true>) : go(trace_kernel<false, true, false>);
@@ -975,7 +991,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   a.column_masks = (uses_column_masks(scene) && !uses_grid(scene, p->flags)) ? 1u : 0u;
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
-  bool const leave_room = d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples;
+  bool const leave_room = (p->flags & RT_HIP_FLAG_LEAVE_ROOM) != 0u ||
+                          (d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples);
   int const blocks = persistent_blocks(scene, p->flags, a.n_items, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   size_t const lds = lds_bytes(scene, p->flags);
@@ -1045,6 +1062,7 @@ void read_stats(const unsigned long long * h, rt_hip_stats * out)
   out->exact_tests = h[5];
   out->lane_trips = h[6];
   out->lane_rounds = h[7];
+  out->cone_tests = h[8];
 }
 
 void destroy_job(rt_hip_job * job)

@@ -5,11 +5,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_DIR = os.path.join(_HERE, "lib")
+# RT_AMD_LIB_DIR: another directory of built libraries (experiment builds of the kernels); default rt_amd/lib
+_LIB_DIR = os.environ.get("RT_AMD_LIB_DIR") or os.path.join(_HERE, "lib")
 
 FLAG_DETERMINISTIC = 1
 FLAG_GRID = 2
 FLAG_PIPELINED = 4
+FLAG_LEAVE_ROOM = 8
 
 RT_HIP_OK = 0
 RT_HIP_ERR_NOT_READY = 3
@@ -58,6 +60,7 @@ class Stats(C.Structure):
         ("exact_tests", C.c_uint64),
         ("lane_trips", C.c_uint64),
         ("lane_rounds", C.c_uint64),
+        ("cone_tests", C.c_uint64),
         ("kernel_ms", C.c_float),
         ("reserved", C.c_uint32),
     ]

@@ -238,7 +238,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     stats6[1] = cnt.queries;
     stats6[2] = cnt.hits;
     stats6[3] = cnt.shaded;
-    stats6[4] = (unsigned long long)cnt.filter_tests * n + 5ull * cnt.cone_tests;
+    stats6[4] = (unsigned long long)cnt.filter_tests * n;
     stats6[5] = cnt.exact_tests;
   }
   return 0;

@@ -34,7 +34,7 @@ def test_rt_host_exports_every_declared_symbol(ffi):
 
 def test_struct_layouts_match_the_header(ffi):
     assert C.sizeof(ffi.Material) == 24 and C.sizeof(ffi.Light) == 28 and C.sizeof(ffi.Camera) == 48
-    assert C.sizeof(ffi.TraceParams) == 32 and C.sizeof(ffi.Stats) == 72
+    assert C.sizeof(ffi.TraceParams) == 32 and C.sizeof(ffi.Stats) == 80
 
 
 def test_calls_before_init_fail_with_a_message(ffi):

@@ -1,19 +1,25 @@
 #!/bin/bash
-# Collects the profiles kept under profiles/: one kernel-trace pass over the benchmark and separate
-# counter passes over one 1080p 16x16 frame.  Run on the GPU box from the repository root:
-#   bash tools/profile.sh <tag>
-# Results land in gpurun_out/prof_<tag>/.
+# Collects the profiles kept under profiles/ for one workload: a kernel-trace pass over the benchmark (one frame
+# at a time, so that every trace launch in the trace runs alone) and separate counter passes over one frame.
+# Run on the GPU box from the repository root:
+#   bash tools/profile.sh <tag> [demo width height samples [spheres [grid]]]     (default: 1 1920 1080 16)
+# Results land in gpurun_out/prof_<tag>/; tools/summarise_profile.py condenses them into profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
+DEMO=${2:-1}; W=${3:-1920}; H=${4:-1080}; S=${5:-16}; SPHERES=${6:-10000}; GRID=${7:-}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+echo "$DEMO $W $H $S $SPHERES $GRID" > "$OUT/workload.txt"
 cd /tmp && export TMPDIR=/tmp
+BENCH_ARGS="--steps 3 --warmup 1 --sync-reduce --no-cpu-baseline --demo $DEMO --width $W --height $H --samples $S --spheres $SPHERES"
+[ -n "$GRID" ] && BENCH_ARGS="$BENCH_ARGS --grid"
 
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- \
-  python3 "$ROOT/bench.py" --steps 5 --warmup 2 --sync-reduce > "$OUT/bench_stdout.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/bench_stdout.log"; exit 1; }
+  python3 "$ROOT/bench.py" $BENCH_ARGS > "$OUT/bench_stdout.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/bench_stdout.log"; exit 1; }
 
-ONE="python3 $ROOT/tools/render_once.py 1 1920 1080 16"
+FLAGS=0; [ -n "$GRID" ] && FLAGS=2
+ONE="python3 $ROOT/tools/render_once.py $DEMO $W $H $S 1 $SPHERES $FLAGS"
 pass() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- $ONE > "$OUT/$name.log" 2>&1 || { echo "pmc pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }

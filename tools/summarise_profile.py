@@ -17,6 +17,11 @@ tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+workload = ["1", "1920", "1080", "16", "10000"]
+if os.path.exists(os.path.join(src, "workload.txt")):
+    workload = open(os.path.join(src, "workload.txt")).read().split()
+demo, w, h, s_row = (int(x) for x in workload[:4])
+grid = len(workload) > 5
 
 shutil.copy(os.path.join(src, "bench", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
 with open(os.path.join(src, "bench_stdout.log")) as f:
@@ -26,9 +31,10 @@ with open(os.path.join(dst, tag + "_bench_line.json"), "w") as f:
 
 totals = {}
 with open(os.path.join(dst, tag + "_pmc_summary.txt"), "w") as out:
-    out.write("rocprofv3 --pmc passes over `python3 tools/render_once.py 1 1920 1080 16` (one 1080p 16x16 pretty_spheres\n"
-              "frame), collected by tools/profile.sh; values summed over the dispatches of each kernel in the run (one\n"
-              "trace launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them (FETCH_SIZE uncorrected).\n\n")
+    out.write("rocprofv3 --pmc passes over `python3 tools/render_once.py %s` (one frame: demo, width, height, samples per\n"
+              "row, repeat, spheres of demo 3, flags), collected by tools/profile.sh; values summed over the dispatches of\n"
+              "each kernel in the run (one trace launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them\n"
+              "(FETCH_SIZE uncorrected).\n\n" % " ".join(workload[:4] + ["1", workload[4], "2" if grid else "0"]))
     for name in ("sq1", "sq2", "fetch", "write"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         with open(os.path.join(src, name, name + "_counter_collection.csv")) as f:
@@ -49,11 +55,13 @@ traffic = {}
 if os.path.exists(traffic_path):
     with open(traffic_path) as f:
         traffic = json.load(f)
-traffic["demo1_1920x1080_s16_g1"] = {
+key = "demo%d_%dx%d_s%d_g1" % (demo, w, h, s_row) + ("_n%s" % workload[4] if demo == 3 else "") + ("_grid" if grid else "")
+traffic[key] = {
     # gfx950: FETCH_SIZE counts half the bytes of wide reads; WRITE_SIZE is exact for 16-byte stores
     "trace_kernel_bytes_per_launch": int((2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]) * 1024),
     "fetch_size_kib": totals["FETCH_SIZE"],
     "write_size_kib": totals["WRITE_SIZE"],
+    "valu_wave_instructions": totals.get("SQ_INSTS_VALU"),
     "source": "profiles/%s_pmc_summary.txt" % tag,
 }
 with open(traffic_path, "w") as f:
