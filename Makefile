@@ -5,7 +5,7 @@ HIPCC    ?= hipcc
 CXX      ?= g++
 ARCH     ?= gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -Irt_amd/csrc
-CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -Irt_amd/host
+CXXFLAGS := -O2 -std=c++17 -ffp-contract=off -fPIC -Wall -Wextra -Iinclude -Irt_amd/host
 
 LIB := rt_amd/lib
 BIN := rt_amd/bin

@@ -49,6 +49,26 @@ int rt_host_render_demo(uint32_t demo, uint32_t scene_seed, uint32_t synthetic_s
                         const rt_hip_trace_params * params, float * rgb, rt_hip_stats * stats, char * err,
                         size_t err_len);
 
+/* One Hit of the object model (ray_tracing/hitable_object.hpp:15-30) with the sphere's index in place of its
+ * material pointer. */
+typedef struct
+{
+  float t;
+  float position[3];
+  float normal[3];
+  uint32_t sphere;
+} rt_host_hit;
+
+/* The ray queries of the object model on the host, for scripts and tests: builds sphere_count Sphere objects
+ * (centers_radii = sphere_count x {cx, cy, cz, radius}) and asks the collection
+ *   mode 0: TraceInHitableCollection -- every hit in [tmin, tmax] by increasing t (hitable_object.hpp:53-69),
+ *   mode 1: TraceNearestInHitableCollection -- the hit a path continues from (hitable_object.hpp:71-87).
+ * Returns the number of hits found; the first min(found, capacity) are written to out.  Plain geometry: no
+ * device is touched and no frame is rendered here. */
+uint32_t rt_host_trace_hits(const float * centers_radii, uint32_t sphere_count, const float origin[3],
+                            const float direction[3], float tmin, float tmax, uint32_t mode, rt_host_hit * out,
+                            uint32_t capacity);
+
 /* App::UpdateTexture (app.cpp:128-138): rgba[i*4+c] = (uint8)(255 * clamp(rgb[i*3+c], 0, 1)), alpha 255. */
 void rt_host_update_texture(const float * rgb, size_t pixels, uint8_t * rgba);
 

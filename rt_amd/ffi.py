@@ -50,6 +50,10 @@ class TraceParams(C.Structure):
     ]
 
 
+class HostHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("position", C.c_float * 3), ("normal", C.c_float * 3), ("sphere", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64),
@@ -125,6 +129,11 @@ HOST_SYMBOLS = {
     "rt_host_render_demo": (
         C.c_int,
         [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(TraceParams), C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t],
+    ),
+    "rt_host_trace_hits": (
+        C.c_uint32,
+        [C.c_void_p, C.c_uint32, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_float, C.c_float, C.c_uint32,
+         C.POINTER(HostHit), C.c_uint32],
     ),
     "rt_host_update_texture": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
 }
@@ -374,6 +383,18 @@ def render_demo(index, p, scene_seed=1, spheres=10000):
     if rc != 0:
         raise HipError("rt_host_render_demo failed (%d): %s" % (rc, err.value.decode()))
     return rgb, stats
+
+
+def trace_hits(scene, origin, direction, tmin, tmax, nearest_only=False, capacity=64):
+    """The object model's ray queries on the host (TraceInHitableCollection / TraceNearestInHitableCollection):
+    returns (number of hits found, [HostHit, ...] the first `capacity` of them)."""
+    host = load_host()
+    out = (HostHit * capacity)()
+    o = (C.c_float * 3)(*[float(x) for x in origin])
+    d = (C.c_float * 3)(*[float(x) for x in direction])
+    n = host.rt_host_trace_hits(scene.centers_radii.ctypes.data, scene.sphere_count, C.byref(o), C.byref(d), tmin, tmax,
+                                1 if nearest_only else 0, out, capacity)
+    return n, [out[i] for i in range(min(n, capacity))]
 
 
 def update_texture(rgb):

@@ -174,6 +174,40 @@ extern "C" int rt_host_render_demo(uint32_t demoIndex, uint32_t sceneSeed, uint3
   return 0;
 }
 
+extern "C" uint32_t rt_host_trace_hits(const float * centersRadii, uint32_t sphereCount, const float origin[3],
+                                       const float direction[3], float tmin, float tmax, uint32_t mode,
+                                       rt_host_hit * out, uint32_t capacity)
+{
+  using namespace ray_tracing;
+  // every sphere gets a material of its own, so that a hit's material pointer names the sphere it lies on
+  std::vector<std::unique_ptr<HitableObject>> objects;
+  objects.reserve(sphereCount);
+  for (uint32_t i = 0; i < sphereCount; ++i)
+  {
+    const float * s = centersRadii + 4u * i;
+    objects.emplace_back(std::make_unique<Sphere>(vec3(s[0], s[1], s[2]), s[3],
+                                                  std::make_shared<material::Matte>(vec3(0.5f, 0.5f, 0.5f))));
+  }
+  Ray const ray(vec3(origin[0], origin[1], origin[2]), vec3(direction[0], direction[1], direction[2]));
+  std::vector<Hit> hits;
+  if (mode == 0u)
+    hits = TraceInHitableCollection(objects, ray, tmin, tmax);
+  else if (auto nearest = TraceNearestInHitableCollection(objects, ray, tmin, tmax))
+    hits.push_back(*nearest);
+  for (uint32_t k = 0; k < hits.size() && k < capacity; ++k)
+  {
+    Hit const & h = hits[k];
+    out[k].t = h.m_parameterT;
+    out[k].position[0] = h.m_position.x; out[k].position[1] = h.m_position.y; out[k].position[2] = h.m_position.z;
+    out[k].normal[0] = h.m_normal.x; out[k].normal[1] = h.m_normal.y; out[k].normal[2] = h.m_normal.z;
+    out[k].sphere = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < sphereCount; ++i)
+      if (objects[i]->GetMaterial() == h.m_material)
+        out[k].sphere = i;
+  }
+  return static_cast<uint32_t>(hits.size());
+}
+
 extern "C" void rt_host_update_texture(const float * rgb, size_t pixels, uint8_t * rgba)
 {
   auto const clamp01 = [](float v) { return std::min(std::max(v, 0.0f), 1.0f); };

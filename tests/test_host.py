@@ -106,3 +106,52 @@ def test_scene_file_errors_name_the_line(ffi, tmp_path):
     path.write_text("scene\n")
     with pytest.raises(ValueError, match="header"):
         ffi.Scene.load(str(path))
+
+
+def test_object_model_ray_queries_match_the_oracle(oracle, ffi, scenes):
+    """Sphere::Trace / TraceNearest and the two collection queries of the host object model
+    (ray_tracing/sphere.cpp:11-81, hitable_object.hpp:53-87) against the oracle's restatement, bit for bit, on
+    random rays through the demo scenes and on the analytic edge cases."""
+    import ctypes as C
+
+    import numpy as np
+
+    lib = oracle.load()
+    rng = np.random.default_rng(11)
+    for demo, spheres in ((1, 0), (2, 0), (3, 200)):
+        scene = scenes(demo, 1, spheres)
+        s = oracle.orc_scene(scene)
+        for _ in range(150):
+            origin = rng.uniform(-6, 6, 3) * [1, 0.3, 1] + [0, 1.5, 0]
+            direction = rng.normal(size=3)
+            if rng.random() < 0.5:
+                direction /= np.linalg.norm(direction)
+            tmin, tmax = (0.001, 1000.0) if rng.random() < 0.7 else (float(rng.uniform(0, 5)), float(rng.uniform(5, 30)))
+            o, d = oracle.f3(origin), oracle.f3(direction)
+            ref = (oracle.OrcHit * 64)()
+            n_ref = lib.orc_trace_all(C.byref(s), C.byref(o), C.byref(d), tmin, tmax, ref, 64)
+            n, hits = ffi.trace_hits(scene, origin, direction, tmin, tmax)
+            assert n == n_ref
+            for a, b in zip(hits, ref):
+                assert a.t == b.t and tuple(a.position) == tuple(b.position) and tuple(a.normal) == tuple(b.normal)
+            # hits with equal t may come in either order (std::sort is not stable): compare spheres as sets per t
+            assert sorted((h.t, h.sphere) for h in hits) == sorted((ref[i].t, ref[i].sphere) for i in range(min(n, 64)))
+            t, pos, nrm = C.c_float(), oracle.F3(), oracle.F3()
+            i_ref = lib.orc_trace_nearest(C.byref(s), C.byref(o), C.byref(d), tmin, tmax, C.byref(t), C.byref(pos),
+                                          C.byref(nrm))
+            n1, near = ffi.trace_hits(scene, origin, direction, tmin, tmax, nearest_only=True)
+            assert n1 == (1 if i_ref >= 0 else 0)
+            if n1:
+                assert near[0].sphere == i_ref and near[0].t == t.value
+                assert tuple(near[0].position) == tuple(pos) and tuple(near[0].normal) == tuple(nrm)
+    # analytic cases: head-on (two hits, nearest at 4), origin inside (far root only; TraceNearest misses), behind
+    one = ffi.Scene.build([(0.0, 0.0, 5.0, 1.0, 0)], [(0, (0.5, 0.5, 0.5), 0.7, 0.0)], [],
+                          dict(position=(0, 0, 0), direction=(0, 0, 1)))
+    n, hits = ffi.trace_hits(one, (0, 0, 0), (0, 0, 1), 0.001, 1000.0)
+    assert n == 2 and (hits[0].t, hits[1].t) == (4.0, 6.0) and tuple(hits[0].normal) == (0.0, 0.0, -1.0)
+    n, hits = ffi.trace_hits(one, (0, 0, 5), (0, 0, 1), 0.001, 1000.0)
+    assert n == 1 and hits[0].t == 1.0
+    assert ffi.trace_hits(one, (0, 0, 5), (0, 0, 1), 0.001, 1000.0, nearest_only=True)[0] == 0
+    assert ffi.trace_hits(one, (0, 0, 0), (0, 0, -1), 0.001, 1000.0)[0] == 0
+    n, hits = ffi.trace_hits(one, (1.0, 0, 0), (0, 0, 1), 0.001, 1000.0)  # tangent: one hit at -b / 2a
+    assert n == 1 and hits[0].t == 5.0
