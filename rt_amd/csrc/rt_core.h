@@ -783,13 +783,12 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
 //                     tile_data(primary)
-// One axis of a walk through the uniform grid: the cell coordinate, the ray parameter at the next wall and
-// the parameter step from wall to wall.
+// One axis of a walk through the uniform grid: the cell coordinate and the ray parameter at the next wall.
 struct GridAxis
 {
   float oo, dd, inv;  // origin relative to the grid, direction component and its reciprocal
   int c, step;
-  float t_next, t_delta;
+  float t_next;
 
   // Narrows [t0, t1] to the slab [0, extent]; false if the ray misses it.
   RT_MEMBER bool clip(float origin, float dir, float extent, float & t0, float & t1)
@@ -818,27 +817,27 @@ struct GridAxis
     {
       step = 1;
       t_next = ((float)(ci + 1) * cell - oo) * inv;
-      t_delta = cell * inv;
     }
     else if (dd < 0.0f)
     {
       step = -1;
       t_next = ((float)ci * cell - oo) * inv;
-      t_delta = -cell * inv;
     }
     else
     {
       step = 0;
       t_next = 3.0e38f;
-      t_delta = 0.0f;
     }
   }
 
-  // Steps into the next cell; false when that leaves the grid.
-  RT_MEMBER bool advance(int dim)
+  // Steps into the next cell; false when that leaves the grid.  The parameter of the next wall is taken from the
+  // cell index each time, not summed up wall by wall: over hundreds of cells a running sum drifts by more than
+  // the margin by which spheres are listed in neighbouring cells.
+  RT_MEMBER bool advance(int dim, float cell)
   {
     c += step;
-    t_next += t_delta;
+    if (step != 0)
+      t_next = ((float)(c + (step > 0 ? 1 : 0)) * cell - oo) * inv;
     return c >= 0 && c < dim;
   }
 };
@@ -911,11 +910,11 @@ RT_FN void grid_trace(const TraceArgs & A, Env & env, bool active, f3 o, f3 d, f
       return;
     bool inside;
     if (x_first)
-      inside = ax[0].advance((int)A.grid_dim[0]);
+      inside = ax[0].advance((int)A.grid_dim[0], A.grid_cell);
     else if (y_first)
-      inside = ax[1].advance((int)A.grid_dim[1]);
+      inside = ax[1].advance((int)A.grid_dim[1], A.grid_cell);
     else
-      inside = ax[2].advance((int)A.grid_dim[2]);
+      inside = ax[2].advance((int)A.grid_dim[2], A.grid_cell);
     if (!inside)
       return;
   }

@@ -5,6 +5,8 @@
 //   rt-scene 1
 //   # comment
 //   camera     px py pz  dx dy dz          (direction need not be normalised)
+//   lens       fov znear zfar            (optional; field of view in radians.  Default: the reference's fixed
+//                                         2 pi / 3, 0.001, 1000 of ray_tracing/frame.hpp:70-72)
 //   background r g b
 //   material   <name> matte r g b
 //   material   <name> metal r g b roughness refraction
@@ -89,6 +91,13 @@ private:
         m_frame->SetCameraPosition(p);
         m_frame->SetCameraDirection(d);
       }
+      else if (key == "lens")
+      {
+        float fov = 0.0f, znear = 0.0f, zfar = 0.0f;
+        if (!(in >> fov >> znear >> zfar) || !(fov > 0.0f) || !(znear > 0.0f) || !(zfar > znear))
+          return Fail(line, "lens needs a field of view, znear and zfar (0 < znear < zfar)");
+        m_frame->SetLens(fov, znear, zfar);
+      }
       else if (key == "background")
       {
         vec3 c;
@@ -166,6 +175,7 @@ inline bool WriteSceneFile(std::string const & path, rt_hip_camera const & cam, 
   std::fprintf(f, "rt-scene 1\n");
   std::fprintf(f, "camera %.9g %.9g %.9g %.9g %.9g %.9g\n", cam.position[0], cam.position[1], cam.position[2],
                cam.direction[0], cam.direction[1], cam.direction[2]);
+  std::fprintf(f, "lens %.9g %.9g %.9g\n", cam.fov, cam.znear, cam.zfar);
   std::fprintf(f, "background %.9g %.9g %.9g\n", cam.background[0], cam.background[1], cam.background[2]);
   for (uint32_t i = 0; i < materialCount; ++i)
   {

@@ -55,6 +55,15 @@ public:
   // Stored normalised, as the reference does (ray_tracing/frame.cpp:79-82).
   void SetCameraDirection(vec3 const & dir) { m_cameraDirection = normalize(dir); }
 
+  // Field of view (radians) and the near / far planes.  Not in the reference, whose lens is fixed at the defaults
+  // below (ray_tracing/frame.hpp:70-72); scene files may carry another one.
+  void SetLens(float fov, float znear, float zfar)
+  {
+    m_fov = fov;
+    m_znear = znear;
+    m_zfar = zfar;
+  }
+
 protected:
   std::shared_ptr<ColorBuffer> m_buffer;
   uint32_t m_width = 0;

@@ -37,11 +37,12 @@ def forward_ok(scene):
     return bool(load().emu_forward_ok(C.cast(scene.materials, C.c_void_p), scene.material_count))
 
 
-def render(scene, p, tile_size=0, column_masks=False, forward=False, grid=False, share=False, general_lights=False):
+def render(scene, p, tile_size=0, column_masks=False, forward=False, grid=False, share=False, general_lights=False,
+           cones=True):
     lib = load()
     rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
     stats = np.zeros(6, dtype=np.uint64)
-    mode = (1 if column_masks else 0) | (2 if forward else 0) | (4 if grid else 0) | (8 if share else 0) | (16 if general_lights else 0)
+    mode = (1 if column_masks else 0) | (2 if forward else 0) | (4 if grid else 0) | (8 if share else 0) | (16 if general_lights else 0) | (0 if cones else 32)
     rc = lib.emu_render_mode(scene.centers_radii.ctypes.data, scene.material_index.ctypes.data, scene.sphere_count,
                              C.cast(scene.materials, C.c_void_p), scene.material_count,
                              C.cast(scene.lights, C.c_void_p), scene.light_count,

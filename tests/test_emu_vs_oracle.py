@@ -216,3 +216,42 @@ def test_grid_walk_with_rays_along_the_axes(oracle, ffi):
     out, es = emu_ffi.render(scene, p, grid=True)
     assert rel_err(ref, out).max() < 2e-6
     assert es["hit_queries"] == rs.hit_queries
+
+
+def long_row_scene(ffi, count=500):
+    """A row of `count` small spheres along x, seen at a grazing angle from one end: grid walks of hundreds of
+    cells, far from the origin of the walk."""
+    mats = [(0, (0.6, 0.6, 0.6), 0.7, 0.0), (1, (0.9, 0.7, 0.3), 0.1, 0.1), (2, (0.8, 0.9, 0.9), 0.0, 0.85)]
+    spheres = [(0.0, -1000.4, 0.0, 1000.0, 0)]
+    for i in range(count):
+        spheres.append((float(i) * 0.9, 0.05 * ((i * 7) % 5), 0.3 * ((i * 3) % 4 - 1.5), 0.3 + 0.02 * (i % 3), i % 3))
+    light = np.array([-0.3, -1.0, 0.2]) / np.linalg.norm([-0.3, -1.0, 0.2])
+    return ffi.Scene.build(spheres, mats, [(tuple(light), (1.0, 1.0, 1.0))],
+                           dict(position=(-3.0, 0.8, 0.1), direction=(1.0, -0.004, 0.0), background=(0.8, 0.85, 0.9)))
+
+
+def test_grid_walk_over_hundreds_of_cells(ffi):
+    """Long walks at a grazing angle: the wall parameters must not drift away from the cells the spheres are listed
+    in.  Same frame and counters as the linear scan, bit for bit."""
+    scene = long_row_scene(ffi)
+    for flags, seed in ((ffi.FLAG_DETERMINISTIC, 1), (0, 3)):
+        p = ffi.params(64, 24, 2, flags=flags, seed=seed)
+        brute, sb = emu_ffi.render(scene, p, forward=True)
+        grid, sg = emu_ffi.render(scene, p, forward=True, grid=True)
+        np.testing.assert_array_equal(grid, brute)
+        for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces"):
+            assert sg[key] == sb[key]
+        assert sb["hit_queries"] > 0.3 * sb["samples"]  # the row is in view
+
+
+@pytest.mark.parametrize("demo,spheres", [(1, 0), (2, 0), (3, 300)])
+def test_shadow_cones_change_no_bit(ffi, scenes, demo, spheres):
+    """Filtering the five shadow rays as one cone first, or one by one against every sphere: same frame, same
+    counters, exact tests included."""
+    scene = scenes(demo, 1, spheres)
+    for flags, seed in ((ffi.FLAG_DETERMINISTIC, 1), (0, 9)):
+        p = ffi.params(48, 36, 2, flags=flags, seed=seed)
+        a, sa = emu_ffi.render(scene, p, forward=True)
+        b, sb = emu_ffi.render(scene, p, forward=True, cones=False)
+        np.testing.assert_array_equal(a, b)
+        assert sa == sb

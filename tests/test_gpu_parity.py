@@ -247,6 +247,20 @@ def test_grid_walk_equals_testing_every_sphere(hip, oracle, ffi, scenes, spheres
     assert rel_err(ref, out).max() < 1e-4 and st.hit_queries == rs.hit_queries
 
 
+def test_grid_walk_over_hundreds_of_cells(hip, ffi):
+    """A row of 500 spheres seen at a grazing angle: walks of hundreds of cells far from where they start."""
+    from test_emu_vs_oracle import long_row_scene
+
+    scene = long_row_scene(ffi)
+    for flags, seed in ((ffi.FLAG_DETERMINISTIC, 1), (0, 3)):
+        brute, sb = hip.render(scene, ffi.params(320, 120, 3, flags=flags, seed=seed))
+        grid, sg = hip.render(scene, ffi.params(320, 120, 3, flags=flags | ffi.FLAG_GRID, seed=seed))
+        np.testing.assert_array_equal(grid, brute)
+        assert (sg.samples, sg.ray_queries, sg.hit_queries, sg.shaded_bounces) == \
+               (sb.samples, sb.ray_queries, sb.hit_queries, sb.shaded_bounces)
+        assert sg.sphere_tests == 0 and sb.hit_queries > 0.3 * sb.samples
+
+
 def test_grid_flag_is_ignored_for_small_scenes(hip, ffi, scenes):
     scene = scenes(1)
     a, sa = hip.render(scene, ffi.params(64, 48, 2, seed=2))

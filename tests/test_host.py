@@ -93,6 +93,20 @@ def test_scene_file_round_trip(ffi, scenes, tmp_path):
             assert list(scene.lights[i].color) == list(back.lights[i].color)
         for field in ("position", "direction", "background"):
             np.testing.assert_allclose(list(getattr(back.camera, field)), list(getattr(scene.camera, field)), rtol=3e-7)  # the direction is normalised again on load
+        assert (back.camera.fov, back.camera.znear, back.camera.zfar) == (scene.camera.fov, scene.camera.znear, scene.camera.zfar)
+    # a lens other than the reference's fixed one survives the file too
+    scene = scenes(1)
+    import copy
+    odd = ffi.Scene(scene.centers_radii, scene.material_index, scene.materials, scene.lights, copy.copy(scene.camera))
+    odd.material_count, odd.light_count = scene.material_count, scene.light_count
+    odd.camera.fov, odd.camera.znear, odd.camera.zfar = 1.25, 0.01, 250.0
+    path = tmp_path / "lens.rtscene"
+    odd.save(str(path))
+    back = ffi.Scene.load(str(path))
+    assert (back.camera.fov, back.camera.znear, back.camera.zfar) == (odd.camera.fov, odd.camera.znear, odd.camera.zfar)
+    path.write_text("rt-scene 1\nlens 1.0 0.5 0.1\n")
+    with pytest.raises(ValueError, match="lens needs"):
+        ffi.Scene.load(str(path))
 
 
 def test_scene_file_errors_name_the_line(ffi, tmp_path):
