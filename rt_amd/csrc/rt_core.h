@@ -124,6 +124,7 @@ RT_FN float hw_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 RT_FN uint32_t hw_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 RT_FN int hw_clz(uint32_t x) { return __clz((int)x); }
+RT_FN int hw_clz64(unsigned long long x) { return __clzll((long long)x); }
 RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
 // mask = 2 * mask + (the sign bit of x): one v_alignbit_b32.
@@ -140,6 +141,7 @@ RT_FN float hw_fma(float a, float b, float c) { return a * b + c; }
 RT_FN uint32_t hw_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 RT_FN uint32_t hw_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 RT_FN int hw_clz(uint32_t x) { return __builtin_clz(x); }
+RT_FN int hw_clz64(unsigned long long x) { return __builtin_clzll(x); }
 RT_FN uint32_t f2u(float f)
 {
   uint32_t u;
@@ -761,6 +763,23 @@ RT_FN uint32_t filter_sphere_shadow(f4 s, f3 o, const f3 (&dir)[RT_RAYS])
   return ~rejected & ((1u << RT_LIGHT_SAMPLES) - 1u);
 }
 
+// Candidates of a group of two chunks as one 64-bit mask with sphere j of the group in bit 63 - j (the chunk masks
+// hold entry j of a chunk in bit count - 1 - j).
+RT_FN unsigned long long group_mask(uint32_t lo, uint32_t count_lo, uint32_t hi, uint32_t count_hi)
+{
+  uint32_t const top = lo << (32u - count_lo);  // 1 <= count_lo <= 32
+  uint32_t const bottom = (count_hi != 0u) ? (hi << (32u - count_hi)) : 0u;
+  return ((unsigned long long)top << 32) | (unsigned long long)bottom;
+}
+
+// Takes the candidate with the lowest sphere index out of a (non-empty) group mask; returns its index in the group.
+RT_FN uint32_t pop_group(unsigned long long & mask)
+{
+  uint32_t const j = (uint32_t)hw_clz64(mask);
+  mask &= ~(0x8000000000000000ull >> j);
+  return j;
+}
+
 // Takes the candidate with the lowest sphere index out of a chunk mask; returns its index in the chunk.
 RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 {
@@ -1008,81 +1027,94 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
   near_i = -1;
   near_t = 0.0f;
   constexpr uint32_t kShadowRays = (1u << RT_LIGHT_SAMPLES) - 1u;
+  constexpr uint32_t kGroup = 2u * RT_CHUNK;
   for (uint32_t k = 0; k < env.tiles(); ++k)
   {
     uint32_t const tile_count = env.load_tile(k, false);
     uint32_t const tile_base = env.tile_base(k);
     const f4 * sph = env.tile_data(false);
-    for (uint32_t c0 = 0; c0 < tile_count; c0 += RT_CHUNK)
+    // The filter runs chunk by chunk (one 32-bit mask per test), the candidates are resolved per group of two
+    // chunks: the loops below go round as often as the lane of the wave with the most candidates needs, so one
+    // loop over 64 spheres takes fewer trips than two loops over 32.
+    for (uint32_t c0 = 0; c0 < tile_count; c0 += kGroup)
     {
-      uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
-      uint32_t cone_mask, ray_mask;
+      uint32_t const count_lo = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
+      uint32_t const rest = tile_count - c0 - count_lo;
+      uint32_t const count_hi = (rest < RT_CHUNK) ? rest : RT_CHUNK;
+      uint32_t cone_lo, ray_lo, cone_hi = 0u, ray_hi = 0u;
       RT_REGION(cnt, 6);
-      filter_chunk_2<Env::kFilterUnroll>(sph + c0, count, o, cone, dir[RT_RAYS - 1], cone_mask, ray_mask);
+      filter_chunk_2<Env::kFilterUnroll>(sph + c0, count_lo, o, cone, dir[RT_RAYS - 1], cone_lo, ray_lo);
+      if (count_hi != 0u)
+        filter_chunk_2<Env::kFilterUnroll>(sph + c0 + RT_CHUNK, count_hi, o, cone, dir[RT_RAYS - 1], cone_hi, ray_hi);
       RT_REGION(cnt, 7);
-      cone_mask = ((live & kShadowRays) != 0u) ? cone_mask : 0u;
-      ray_mask = ((live >> (RT_RAYS - 1)) & 1u) ? ray_mask : 0u;
-      if (!env.any_wave((cone_mask | ray_mask) != 0u))
+      // sphere j of the group in bit 63 - j: the lowest index is the highest bit
+      unsigned long long cone_mask = group_mask(cone_lo, count_lo, cone_hi, count_hi);
+      unsigned long long ray_mask = group_mask(ray_lo, count_lo, ray_hi, count_hi);
+      cone_mask = ((live & kShadowRays) != 0u) ? cone_mask : 0ull;
+      ray_mask = ((live >> (RT_RAYS - 1)) & 1u) ? ray_mask : 0ull;
+      if (!env.any_wave((cone_mask | ray_mask) != 0ull))
         continue;
       // The spheres the cone may touch, against the five shadow rays themselves: one sphere per lane and
       // iteration, no branches inside.
-      uint32_t mask[RT_RAYS];
+      unsigned long long mask[RT_RAYS];
 #pragma unroll
       for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
-        mask[r] = 0u;
+        mask[r] = 0ull;
       mask[RT_RAYS - 1] = ray_mask;
-      while (env.any_wave(cone_mask != 0u))
+      while (env.any_wave(cone_mask != 0ull))
       {
-        bool const h = cone_mask != 0u;
-        uint32_t m = h ? cone_mask : 1u;
-        uint32_t const bit = 31u - (uint32_t)hw_clz(m);
-        uint32_t const pass = h ? filter_sphere_shadow(sph[c0 + (count - 1u - bit)], o, dir) : 0u;
+        bool const h = cone_mask != 0ull;
+        unsigned long long const m = h ? cone_mask : 1ull;
+        uint32_t const j = (uint32_t)hw_clz64(m);
+        unsigned long long const bit = 0x8000000000000000ull >> j;
+        uint32_t const pass = h ? filter_sphere_shadow(sph[c0 + (h ? j : 0u)], o, dir) : 0u;
         cnt.cone_tests += h ? 1u : 0u;
 #pragma unroll
         for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
-          mask[r] |= ((pass >> r) & 1u) << bit;
-        cone_mask = h ? (m & ~(1u << bit)) : 0u;
+          mask[r] |= ((pass >> r) & 1u) ? bit : 0ull;
+        cone_mask = h ? (m & ~bit) : 0ull;
       }
-      uint32_t any_mask = 0;
+      unsigned long long any_mask = 0ull;
 #pragma unroll
       for (int r = 0; r < RT_RAYS; ++r)
       {
-        mask[r] = ((live >> r) & 1u) ? mask[r] : 0u;
+        mask[r] = ((live >> r) & 1u) ? mask[r] : 0ull;
         any_mask |= mask[r];
       }
-      if (!env.any_wave(any_mask != 0u))
+      if (!env.any_wave(any_mask != 0ull))
         continue;
       // Candidates are resolved two rays at a time, without branches inside an iteration: the two exact
       // intersections are independent chains of dependent instructions (IEEE sqrt and division) and interleave.
       // Shadow rays: existence of a hit in [0.001, 1000] is all TraceLight uses.  Scattered ray (the last one):
-      // nearest hit; secondary hits start at 0.001 (demos/demo_frame_cpu.cpp:53).
+      // nearest hit, lowest index first so that the first of equal distances wins; secondary hits start at 0.001
+      // (demos/demo_frame_cpu.cpp:53).
       uint32_t const base = tile_base + c0;
 #pragma unroll
       for (int r = 0; r < RT_RAYS; r += 2)
       {
-        while (env.any_wave((mask[r] | mask[r + 1]) != 0u))
+        while (env.any_wave((mask[r] | mask[r + 1]) != 0ull))
         {
-          bool const h0 = mask[r] != 0u, h1 = mask[r + 1] != 0u;
-          uint32_t m0 = h0 ? mask[r] : 1u, m1 = h1 ? mask[r + 1] : 1u;
-          int const i0 = (int)(base + pop_candidate(m0, count)), i1 = (int)(base + pop_candidate(m1, count));
+          bool const h0 = mask[r] != 0ull, h1 = mask[r + 1] != 0ull;
+          unsigned long long m0 = h0 ? mask[r] : 0x8000000000000000ull, m1 = h1 ? mask[r + 1] : 0x8000000000000000ull;
+          int const i0 = (int)(base + pop_group(m0)), i1 = (int)(base + pop_group(m1));
           float t0, t1;
           bool const hit0 = exact_hit_flat(o, dir[r], a[r], env.sphere(i0), 0.001f, 1000.0f, t0) && h0;
           bool const last = (r + 1 == RT_RAYS - 1);
           bool const hit1 = exact_hit_flat(o, dir[r + 1], a[r + 1], env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1) && h1;
           cnt.exact_tests += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
           live = hit0 ? (live & ~(1u << r)) : live;
-          mask[r] = (hit0 || !h0) ? 0u : m0;
+          mask[r] = (hit0 || !h0) ? 0ull : m0;
           if (last)
           {
             bool const nearer = hit1 && (near_i < 0 || t1 < near_t);
             near_i = nearer ? i1 : near_i;
             near_t = nearer ? t1 : near_t;
-            mask[r + 1] = h1 ? m1 : 0u;
+            mask[r + 1] = h1 ? m1 : 0ull;
           }
           else
           {
             live = hit1 ? (live & ~(1u << (r + 1))) : live;
-            mask[r + 1] = (hit1 || !h1) ? 0u : m1;
+            mask[r + 1] = (hit1 || !h1) ? 0ull : m1;
           }
         }
       }

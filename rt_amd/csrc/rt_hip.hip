@@ -973,6 +973,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
   unsigned long long const cost = uses_grid(scene, p->flags) ? 1u : std::max<unsigned long long>(1u, scene->n_spheres / 64u);
   a.batch_items = batch_items(p, g_lib.compute_units, cost);
+  if (const char * v = std::getenv("RT_HIP_BATCH_ITEMS"))  // experiments: reservation size in items (a multiple of 64)
+    a.batch_items = std::max<uint32_t>(kItemBatch, (uint32_t)std::strtoul(v, nullptr, 10) / kItemBatch * kItemBatch);
   // A frame that overlaps with the next one on another stream keeps full reservations to the end: the next
   // frame's waves fill what its end leaves idle, and the smaller reservations would only cost throughput.
   a.batch_min = (p->flags & RT_HIP_FLAG_PIPELINED) ? a.batch_items : batch_min(p, a.batch_items, cost);
