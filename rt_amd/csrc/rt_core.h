@@ -374,7 +374,8 @@ struct Lane
   float sdx, dyp;   // sdx of the column, dy of the pixel (ray_tracing/frame.cpp:49,52,58)
   f3 sum;
   bool alive, need_item;
-  uint32_t cm0, cm1;  // candidate masks of the column (spheres 0..31, 32..63) when column masks are on
+  uint32_t cm0, cm1;  // candidates of the column (sphere j in bit 31 - j of cm0, sphere 32 + j in bit 31 - j of cm1)
+                      // when column masks are on
   // current path
   f3 acc_l;           // forward accumulation: product of the l entries pushed so far
   float acc_e;        // ... and of emissivity_k ^ k
@@ -521,9 +522,12 @@ RT_FN ColumnEntry prepare_column(const TraceArgs & A, const f4 * camtab, uint32_
   float const sdy = e.dyp - A.cell_y * mid;
   f3 const v = (A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * e.sdx;
   f3 const dc = normalize3_fast(v);
+  // the candidates as a group mask (sphere j in bit 63 - j): cm0 the upper word, spheres 0..31, cm1 the lower
   uint32_t const c0 = (A.n_padded < RT_CHUNK) ? A.n_padded : RT_CHUNK;
-  e.cm0 = filter_chunk_1(camtab, c0, dc);
-  e.cm1 = (A.n_padded > RT_CHUNK) ? filter_chunk_1(camtab + RT_CHUNK, A.n_padded - RT_CHUNK, dc) : 0u;
+  e.cm0 = (c0 != 0u) ? (filter_chunk_1(camtab, c0, dc) << (32u - c0)) : 0u;
+  e.cm1 = (A.n_padded > RT_CHUNK)
+              ? (filter_chunk_1(camtab + RT_CHUNK, A.n_padded - RT_CHUNK, dc) << (32u - (A.n_padded - RT_CHUNK)))
+              : 0u;
   e.sy0 = first_sample(A, item);
   e.pad = 0u;
   return e;
@@ -973,11 +977,23 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
   best_t = 0.0f;
   if (A.column_masks != 0u)
   {
-    uint32_t const c0 = (A.n_padded < RT_CHUNK) ? A.n_padded : RT_CHUNK;
+    // the column's candidates, sphere j in bit 63 - j (prepare_column): one loop over all of them
     RT_REGION(cnt, 2);
-    resolve_primary(A, env, active ? cm0 : 0u, 0u, c0, dir, a, best_t, best_i, cnt);
-    if (A.n_padded > RT_CHUNK)
-      resolve_primary(A, env, active ? cm1 : 0u, RT_CHUNK, A.n_padded - RT_CHUNK, dir, a, best_t, best_i, cnt);
+    unsigned long long mask = active ? (((unsigned long long)cm0 << 32) | (unsigned long long)cm1) : 0ull;
+    while (env.any_wave(mask != 0ull))
+    {
+      if (mask != 0ull)
+      {
+        int const i = (int)pop_group(mask);
+        float t;
+        cnt.exact_tests += 1;
+        if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t) && (best_i < 0 || t < best_t))
+        {
+          best_i = i;
+          best_t = t;
+        }
+      }
+    }
     RT_REGION(cnt, 3);
     return;
   }
