@@ -349,6 +349,11 @@ RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float 
 // results (a negative discriminant is rejected whatever its square root turns into).
 RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Keeps 4a and 2a from being computed ahead of the resolution loops for all six rays (a dozen registers held
+  // across the whole pass for two multiplications per test).
+  asm volatile("" : "+v"(a));
+#endif
   f3 const d = o - mk3(s.x, s.y, s.z);
   float const b = 2.0f * dot3(d, dir);
   float const c = dot3(d, d) - s.w;

@@ -26,8 +26,14 @@ def test_job_runs_asynchronously_and_snapshots_progress(hip, ffi, scenes):
     job = hip.start(scene, p)
     launch = time.perf_counter() - t0
     assert hip.poll(job) == ffi.RT_HIP_ERR_NOT_READY
-    snap = hip.snapshot(job, p)  # must not wait for the trace
+    snap = hip.snapshot(job, p)  # must not wait for the trace (the first one also makes the snapshot buffers)
+    t1 = time.perf_counter()
+    snap = hip.snapshot(job, p)
+    snapshot_ms = (time.perf_counter() - t1) * 1e3
     still_running = hip.poll(job) == ffi.RT_HIP_ERR_NOT_READY
+    print("snapshot of a running 3840x2160 frame: %.2f ms of host time (accumulate + resolve on the copy stream, "
+          "99.5 MB into pinned memory, one memcpy)" % snapshot_ms)
+    assert snapshot_ms < 60.0
     final, st = hip.finish(job, p)
     assert launch < 0.02  # returned long before the frame finished
     # a snapshot holds finished columns only: every pixel is at most its final value, unfinished ones darker
