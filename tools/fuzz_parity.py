@@ -1,6 +1,7 @@
 """Random small frames through the HIP backend against the oracle: sizes, samples per row, slices, flags and
 scenes drawn at random.  Deterministic frames must match the oracle per pixel (1e-4 relative) with equal query
-counters; stochastic frames must not change a bit when sample sharing is switched off or RT_HIP_FLAG_PIPELINED is set.
+counters; stochastic frames must not change a bit when sample sharing is switched off, RT_HIP_FLAG_PIPELINED is set
+or the shadow cones are switched off (scenes with several lights of any length included).
 
 python tools/fuzz_parity.py [SECONDS] [SEED]
 """
@@ -18,7 +19,44 @@ from rt_amd import ffi  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = ffi.HipRenderer(0)
-scenes = [ffi.Scene.demo(1, 1), ffi.Scene.demo(2, 1), ffi.Scene.demo(3, 1, 100), ffi.Scene.demo(3, 1, 700)]
+
+
+def random_scene(k):
+    """A few dozen spheres of all materials under one to three lights whose directions are not normalised (the
+    shadow cone's opening depends on the light vector's length; a short one has no cone at all)."""
+    g = np.random.default_rng(1000 + k)
+    mats = [(0, (0.6, 0.6, 0.6), 0.7, 0.0)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0)]
+    for _ in range(int(g.integers(5, 60))):
+        kind = int(g.integers(0, 3))
+        mats.append((kind, tuple(float(x) for x in g.uniform(0.1, 1.0, 3)), float(g.uniform(0.0, 0.9)) if kind == 1 else 0.7,
+                     float(g.uniform(0.8, 0.9)) if kind == 2 else float(g.uniform(0.0, 0.2))))
+        rad = float(g.uniform(0.15, 0.6))
+        spheres.append((float(g.uniform(-4, 4)), rad - 1.0 + float(g.uniform(0, 1.5)), float(g.uniform(0, 8)), rad, len(mats) - 1))
+    lights = []
+    for _ in range(int(g.integers(1, 4))):
+        d = g.normal(size=3)
+        d[1] = -abs(d[1]) - 0.3
+        d *= float(g.choice([0.2, 0.27, 0.5, 1.0, 1.0, 3.0])) / np.linalg.norm(d)
+        lights.append((tuple(float(x) for x in d), tuple(float(x) for x in g.uniform(0.2, 1.0, 3))))
+    return ffi.Scene.build(spheres, mats, lights, dict(position=(0.0, 0.8, -4.0), direction=(0.0, -0.15, 1.0),
+                                                        background=(0.8, 0.85, 0.9)))
+
+
+def without_cones(make):
+    os.environ["RT_HIP_NO_CONES"] = "1"
+    try:
+        scene = make()
+        r.upload(scene)
+    finally:
+        del os.environ["RT_HIP_NO_CONES"]
+    return scene
+
+
+makers = [lambda: ffi.Scene.demo(1, 1), lambda: ffi.Scene.demo(2, 1), lambda: ffi.Scene.demo(3, 1, 100),
+          lambda: ffi.Scene.demo(3, 1, 700)] + [(lambda k=k: random_scene(k)) for k in range(8)]
+scenes = [m() for m in makers]
+plain = [without_cones(m) for m in makers]
 cases = worst = 0
 worst_case = ""
 t_end = time.time() + budget
@@ -32,7 +70,7 @@ while time.time() < t_end:
     g = int(rng.choice([1, 1, 2, 3, 5, 8, 16]))
     idx = int(rng.integers(g))
     depth = int(rng.choice([0, 1, 3]))
-    grid = ffi.FLAG_GRID if (si >= 2 and rng.random() < 0.5) else 0
+    grid = ffi.FLAG_GRID if (si in (2, 3) and rng.random() < 0.5) else 0
     seed = int(rng.integers(1, 1000))
     det = ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC | grid, max_depth=depth, slice_index=idx, slice_count=g)
     ref, rs = oracle_ffi.render(scene, ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC, max_depth=depth, slice_index=idx,
@@ -50,8 +88,12 @@ while time.time() < t_end:
     del os.environ["RT_HIP_NO_SHARING"]
     c, sc = r.render(scene, ffi.params(w, h, s, flags=grid | ffi.FLAG_PIPELINED, seed=seed, max_depth=depth, slice_index=idx,
                                        slice_count=g))
+    d, sd = r.render(plain[si], sto)  # the same scene without shadow cones
     stable = np.array_equal(a, b) and np.array_equal(a, c) and sa.ray_queries == sb.ray_queries == sc.ray_queries
+    stable = stable and np.array_equal(a, d) and (sa.hit_queries, sa.exact_tests) == (sd.hit_queries, sd.exact_tests)
     cases += 1
+    if cases % 50 == 0:
+        print("%d cases so far, worst deterministic error %.3g" % (cases, worst), flush=True)
     if err >= 1e-4 or not same or not stable or not np.isfinite(out).all():
         print("FAILED: scene %d %dx%d s=%d slice %d/%d depth %d grid %d seed %d: err %.3g counters %s stable %s" % (
             si, w, h, s, idx, g, depth, grid, seed, err, same, stable))
