@@ -277,12 +277,13 @@ struct TraceArgs
   // region * share_depth, 0) to `splits`, and fold_split adds the shared colours in sample order afterwards, so
   // the column sum is the same floating-point sum whoever traced the samples.
   float * shared;
+  size_t shared_off;          // shared - partial, in floats: the colours of shared samples lie behind the column sums
   u4 * splits;
   uint32_t * split_count;
   uint32_t share_depth;       // samples at the end of a column that may be shared (<= s_row)
 };
 
-#define RT_REGION_COUNT 12
+#define RT_REGION_COUNT 14
 struct LaneCounters
 {
   uint32_t samples, queries, hits, shaded, exact_tests;
@@ -306,11 +307,15 @@ struct LaneCounters
     (cnt).region[k] += now_ - (cnt).last_tick;                              \
     (cnt).last_tick = now_;                                                 \
   } while (0)
+// Slots 12 and 13 count loop trips of a wave, not time: cone spheres against the five rays, and pairs of exact tests.
+#define RT_COUNT_TRIP(cnt, k) ((cnt).region[k] += 1ull)
 #elif defined(RT_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
 // Listing aid: leaves "; MARK k" comments in the assembly so that instructions can be counted per region.
 #define RT_REGION(cnt, k) asm volatile("; MARK " #k)
+#define RT_COUNT_TRIP(cnt, k) ((void)0)
 #else
 #define RT_REGION(cnt, k) ((void)0)
+#define RT_COUNT_TRIP(cnt, k) ((void)0)
 #endif
 
 // The filter.  With d = C - O and unit D, the ray can hit the sphere in front of O only if
@@ -1084,6 +1089,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       mask[RT_RAYS - 1] = ray_mask;
       while (env.any_wave(cone_mask != 0ull))
       {
+        RT_COUNT_TRIP(cnt, 12);
         bool const h = cone_mask != 0ull;
         unsigned long long const m = h ? cone_mask : 1ull;
         uint32_t const j = (uint32_t)hw_clz64(m);
@@ -1115,6 +1121,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       {
         while (env.any_wave((mask[r] | mask[r + 1]) != 0ull))
         {
+          RT_COUNT_TRIP(cnt, 13);
           bool const h0 = mask[r] != 0ull, h1 = mask[r + 1] != 0ull;
           unsigned long long m0 = h0 ? mask[r] : 0x8000000000000000ull, m1 = h1 ? mask[r + 1] : 0x8000000000000000ull;
           int const i0 = (int)(base + pop_group(m0)), i1 = (int)(base + pop_group(m1));
@@ -1191,8 +1198,10 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       if (need && !L.need_item && L.sy >= L.sy_end)
       {
         bool const shared_sample = (L.slot & RT_SHARED_SLOT) != 0u;
-        float * const dst = shared_sample ? A.shared : A.partial;
-        store3(dst + 3u * (size_t)(L.slot & ~RT_SHARED_SLOT), L.sum);
+        // one base pointer and an offset, not a choice between two pointers (which the compiler turns into a load
+        // of the chosen pointer from the argument block, a memory round trip in every round that ends a column)
+        size_t const at = 3u * (size_t)(L.slot & ~RT_SHARED_SLOT) + (shared_sample ? A.shared_off : (size_t)0);
+        store3(A.partial + at, L.sum);
         if (!shared_sample && L.sy_end < A.s_row)
           env.record_split(L.slot, L.sy_end);
         L.need_item = true;

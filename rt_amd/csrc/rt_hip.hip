@@ -263,6 +263,7 @@ struct WaveEnv
   const f4 * exact;      // LDS: n_padded exact records
   const f4 * mats;       // LDS: 2 * n_materials
   const f4 * lights;     // LDS: RT_LIGHT_RECORDS * n_lights
+  const uint32_t * smat; // LDS: n_padded material indices
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ColumnEntry * batch;   // LDS: this wave's kItemBatch prepared columns (column masks only)
   ItemPool pool;
@@ -274,7 +275,7 @@ struct WaveEnv
   __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
-  __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
+  __device__ __forceinline__ uint32_t sphere_material(int i) const { return smat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[RT_MAT_RECORDS * m + k]; }
   __device__ __forceinline__ f4 light(uint32_t l, uint32_t k) const { return lights[RT_LIGHT_RECORDS * l + k]; }
   __device__ __forceinline__ const float * jitter_table() const { return jitter; }
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     f4 * exact = cam + A.n_padded;
     f4 * mats = exact + A.n_padded;
     f4 * lights = mats + RT_MAT_RECORDS * A.n_materials;
-    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(lights + RT_LIGHT_RECORDS * A.n_lights);
+    uint32_t * smat = reinterpret_cast<uint32_t *>(lights + RT_LIGHT_RECORDS * A.n_lights);
+    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(smat + ((A.n_padded + 3u) & ~3u));
     for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
     {
       sph[i] = A.filter[i];
@@ -503,11 +505,13 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
       mats[i] = A.materials[i];
     for (uint32_t i = threadIdx.x; i < RT_LIGHT_RECORDS * A.n_lights; i += kBlock)
       lights[i] = A.lights[i];
+    for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
+      smat[i] = A.sphere_mat[i];
     __syncthreads();
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
-    WaveEnv env{A, sph, cam, exact, mats, lights, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
+    WaveEnv env{A, sph, cam, exact, mats, lights, smat, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
@@ -776,12 +780,12 @@ bool share_disabled() { return std::getenv("RT_HIP_NO_SHARING") != nullptr; }
 bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }
 
 // LDS of the resident layout: path stacks (scenes whose paths cannot be accumulated forward), the jitter table,
-// three records per sphere, the materials and lights, one prepared-column table per wave.
+// three records and a material index per sphere, the materials and lights, one prepared-column table per wave.
 size_t resident_lds_bytes(const rt_hip_scene * sc)
 {
   return (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS +
          sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + RT_LIGHT_RECORDS * sc->n_lights) +
-         sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
+         sizeof(uint32_t) * (size_t)((sc->n_padded + 3u) & ~3u) + sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
 }
 
 // A scene is staged through LDS in tiles when it is too large to live there whole: too many records for the
@@ -1007,6 +1011,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     a.split_count = reinterpret_cast<uint32_t *>(base);
     a.splits = reinterpret_cast<u4 *>(base + 16);
     a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
+    a.shared_off = (size_t)(a.shared - d_partial);
     a.share_depth = share_depth(p);
   }
   {

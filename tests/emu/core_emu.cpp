@@ -182,7 +182,11 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     env.share_test = true;
     a.share_depth = s_row;
     shared.assign(3u * (size_t)a.n_items * a.share_depth, 0.0f);
-    a.shared = shared.data();
+    // the colours of shared samples are addressed relative to the column sums: one buffer holds both here too
+    partial.resize(partial.size() + shared.size(), 0.0f);
+    a.partial = partial.data();
+    a.shared = partial.data() + 3u * (size_t)a.n_items;
+    a.shared_off = 3u * (size_t)a.n_items;
   }
   // the forward-accumulating loop comes specialised for one light, as in the library (mode bit 4 keeps the
   // general loop for such scenes)
@@ -218,7 +222,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
 
   g_last_split_count = (unsigned long long)env.splits.size();
   for (rtc::u4 const & rec : env.splits)
-    rtc::fold_split(partial.data(), shared.data(), rec, s_row, a.slice_count);
+    rtc::fold_split(partial.data(), a.shared, rec, s_row, a.slice_count);
   if (env.share_test && !env.waiting.empty())
     return 4;
 
