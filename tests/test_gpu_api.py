@@ -304,3 +304,39 @@ def test_same_demo_around_either_frame(oracle, ffi, demo):
     err = np.abs(cpu_rgb - hip_rgb) / np.maximum(np.abs(cpu_rgb), 1e-3)
     assert err.max() < 1e-4
     assert (hs.samples, hs.ray_queries, hs.hit_queries) == (cs.samples, cs.ray_queries, cs.hit_queries)
+
+
+def test_jobs_from_two_threads_on_one_scene(hip, ffi, scenes):
+    """Every job has its own camera table and buffers, so two threads may render different views of one scene at
+    the same time (the scene itself is immutable): each frame equals the one rendered alone."""
+    import copy
+    import threading
+
+    base = scenes(1)
+    views = []
+    for k, shift in enumerate((0.0, 1.5)):
+        s = ffi.Scene(base.centers_radii, base.material_index, base.materials, base.lights, copy.copy(base.camera))
+        s.material_count, s.light_count = base.material_count, base.light_count
+        s.camera.position[0] = base.camera.position[0] + shift
+        views.append((s, ffi.params(320 + 64 * k, 200, 3, seed=5 + k)))
+    handle = hip.upload(base)
+    for s, _ in views:
+        hip._scenes[id(s)] = (handle, s)  # the same device scene, another camera
+    alone = [hip.render(s, p)[0] for s, p in views]
+    results = [[None] * 6 for _ in views]
+
+    def work(i):
+        s, p = views[i]
+        for n in range(6):
+            results[i][n] = hip.render(s, p)[0]
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(views))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s, _ in views:
+        del hip._scenes[id(s)]
+    for i in range(len(views)):
+        for frame in results[i]:
+            np.testing.assert_array_equal(frame, alone[i])
