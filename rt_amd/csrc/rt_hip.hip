@@ -618,6 +618,73 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ 
   }
 }
 
+// The same pass for the common sample counts, through LDS: a lane of colsum_kernel reads its pixel's 12 * S bytes
+// 16 at a time, so one load instruction of a wave touches 64 places 12 * S bytes apart.  Here a wave reads the
+// column sums of kPixels consecutive pixels as one contiguous run, 16 bytes per lane (whole lines per instruction),
+// parks them in its own LDS region (rows padded to an odd length, so that the pixel-per-lane reads that follow hit
+// 64 different banks), and lane p then adds pixel p's columns in increasing sx exactly as colsum_kernel does: same
+// sums, bit for bit.
+template <uint32_t kS, uint32_t kPixels>
+__global__ __launch_bounds__(256) void colsum_lds_kernel(const float * __restrict__ partial, float * __restrict__ planes,
+                                                         uint32_t n)
+{
+  constexpr uint32_t kRow = 3u * kS;        // floats per pixel
+  constexpr uint32_t kPad = kRow | 1u;      // LDS row length: odd
+  static_assert((kPixels * kRow) % 4u == 0u, "a wave's run starts on a 16-byte boundary");
+  __shared__ float lds[4][kPixels * kPad];
+  uint32_t const wave = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+  float * const mine = lds[wave];
+  uint32_t const groups = (n + kPixels - 1u) / kPixels;
+  for (uint32_t group = blockIdx.x * 4u + wave; group < groups; group += gridDim.x * 4u)
+  {
+    uint32_t const p0 = group * kPixels;
+    uint32_t const count = min(kPixels, n - p0);
+    uint32_t const total = count * kRow;
+    const float * const src = partial + (size_t)p0 * kRow;
+    for (uint32_t g = 4u * lane; g < total; g += 256u)
+    {
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (g + 3u < total)
+      {
+        float4 const q = *reinterpret_cast<const float4 *>(src + g);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      }
+      else
+        for (uint32_t j = 0; g + j < total; ++j)
+          v[j] = src[g + j];
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; ++j)
+      {
+        uint32_t const e = g + j, pixel = e / kRow;
+        if (e < total)
+          mine[pixel * kPad + (e - pixel * kRow)] = v[j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < count)
+    {
+      const float * c = mine + lane * kPad;
+      float r = 0.0f, gsum = 0.0f, b = 0.0f;
+#pragma unroll
+      for (uint32_t i = 0; i < kS; ++i, c += 3)
+      {
+        r += c[0];
+        gsum += c[1];
+        b += c[2];
+      }
+      uint32_t const p = p0 + lane;
+      planes[p] = r;
+      planes[n + p] = gsum;
+      planes[2u * (size_t)n + p] = b;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // planes: 3 x n floats; rgb: n x 3 floats.  Each lane takes 4 pixels: three 16-byte loads, three 16-byte
 // stores (48 contiguous bytes), so both sides stream in full lines.
 __global__ __launch_bounds__(256) void resolve_kernel(const float * __restrict__ planes,
@@ -1041,8 +1108,26 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
 int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream)
 {
   uint32_t const n = p->width * p->height;
-  int const blocks = (int)std::min<uint32_t>((n + 255u) / 256u, 256u * 8u);
-  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row);
+  // the sample counts of the reference's demos and of the benchmark go through LDS (whole-line loads)
+  auto through_lds = [&](auto kernel, uint32_t pixels_per_wave) {
+    uint32_t const groups = (n + pixels_per_wave - 1u) / pixels_per_wave;
+    int const blocks = (int)std::min<uint32_t>((groups + 3u) / 4u, 256u * 3u);
+    hipLaunchKernelGGL(kernel, dim3(std::max(blocks, 1)), dim3(256), 0, stream, d_partial, d_planes, n);
+  };
+  switch (std::getenv("RT_HIP_PLAIN_COLSUM") ? 0u : p->samples_in_row)
+  {
+  case 2: through_lds(colsum_lds_kernel<2, 64>, 64u); break;
+  case 4: through_lds(colsum_lds_kernel<4, 64>, 64u); break;
+  case 8: through_lds(colsum_lds_kernel<8, 64>, 64u); break;
+  case 10: through_lds(colsum_lds_kernel<10, 64>, 64u); break;
+  case 16: through_lds(colsum_lds_kernel<16, 64>, 64u); break;
+  case 32: through_lds(colsum_lds_kernel<32, 32>, 32u); break;
+  default:
+  {
+    int const blocks = (int)std::min<uint32_t>((n + 255u) / 256u, 256u * 8u);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row);
+  }
+  }
   RT_CHECK(hipGetLastError());
   return RT_HIP_OK;
 }

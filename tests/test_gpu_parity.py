@@ -301,3 +301,18 @@ def test_slice_rule_on_an_empty_scene(hip, ffi, s_row, slices):
         expect = owned.reshape(h, w)[:, :, None] * bg[None, None, :] / (s_row * s_row)
         np.testing.assert_allclose(out, expect, rtol=1e-5)
         assert st.samples == int(owned.sum())
+
+
+@pytest.mark.parametrize("s", [2, 4, 8, 10, 16, 32])
+def test_accumulate_pass_through_lds_changes_no_bit(hip, ffi, scenes, monkeypatch, s):
+    """The accumulate pass has a variant per common sample count that reads whole lines and transposes them in LDS;
+    RT_HIP_PLAIN_COLSUM keeps the lane-per-pixel kernel.  Same sums in the same order: identical frames, on frames
+    whose pixel count is no multiple of anything."""
+    scene = scenes(1)
+    for w, h in ((131, 67), (64, 64), (1, 1), (257, 3)):
+        p = ffi.params(w, h, s, seed=3)
+        a, _ = hip.render(scene, p)
+        monkeypatch.setenv("RT_HIP_PLAIN_COLSUM", "1")
+        b, _ = hip.render(scene, p)
+        monkeypatch.delenv("RT_HIP_PLAIN_COLSUM")
+        np.testing.assert_array_equal(a, b)
