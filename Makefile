@@ -1,3 +1,5 @@
+# (-Wl,-Bsymbolic: the libraries share inline functions of rt_prep.h; each must call its own copy, not whichever
+# library the process happened to load first.)
 # Builds the shipped libraries in-tree (rt_amd/lib, rt_amd/bin) and, separately, the test-only checkers.
 #   make            -> librt_hip.so (hipcc, gfx950), librt_host.so + rt_cli (g++)
 #   make checkers   -> oracle/librt_oracle.so and tests/emu/libcore_emu.so (never linked into the above)
@@ -16,7 +18,7 @@ all: $(LIB)/librt_hip.so $(LIB)/librt_host.so $(BIN)/rt_cli
 
 $(LIB)/librt_hip.so: rt_amd/csrc/rt_hip.hip $(CORE_HDRS)
 	@mkdir -p $(LIB)
-	$(HIPCC) $(HIPFLAGS) -shared rt_amd/csrc/rt_hip.hip -o $@
+	$(HIPCC) $(HIPFLAGS) -shared -Wl,-Bsymbolic rt_amd/csrc/rt_hip.hip -o $@
 
 $(LIB)/librt_host.so: rt_amd/host/rt_host_capi.cpp rt_amd/host/rt_hip/demo_frame_hip.cpp $(HOST_HDRS) $(LIB)/librt_hip.so
 	$(CXX) $(CXXFLAGS) -shared rt_amd/host/rt_host_capi.cpp rt_amd/host/rt_hip/demo_frame_hip.cpp \
@@ -34,7 +36,7 @@ rt_amd/lib_prof/librt_host.so: $(LIB)/librt_host.so
 	cp $(LIB)/librt_host.so $@
 rt_amd/lib_prof/librt_hip.so: rt_amd/csrc/rt_hip.hip $(CORE_HDRS)
 	@mkdir -p rt_amd/lib_prof
-	$(HIPCC) $(HIPFLAGS) -DRT_PROFILE_REGIONS -shared rt_amd/csrc/rt_hip.hip -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_PROFILE_REGIONS -shared -Wl,-Bsymbolic rt_amd/csrc/rt_hip.hip -o $@
 
 checkers: oracle/librt_oracle.so oracle/librt_oracle_o3.so oracle/liboracle_frame.so tests/emu/libcore_emu.so
 
@@ -48,7 +50,7 @@ oracle/liboracle_frame.so: oracle/frame_cpu.cpp oracle/librt_oracle.so $(HOST_HD
 	$(MAKE) -C oracle liboracle_frame.so
 
 tests/emu/libcore_emu.so: tests/emu/core_emu.cpp $(CORE_HDRS)
-	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -Irt_amd/csrc tests/emu/core_emu.cpp -o $@
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Wl,-Bsymbolic -Iinclude -Irt_amd/csrc tests/emu/core_emu.cpp -o $@
 
 clean:
 	rm -f $(LIB)/*.so $(BIN)/rt_cli tests/emu/libcore_emu.so

@@ -127,6 +127,7 @@ RT_FN int hw_clz(uint32_t x) { return __clz((int)x); }
 RT_FN int hw_clz64(unsigned long long x) { return __clzll((long long)x); }
 RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
+RT_FN float hw_abs(float a) { return __builtin_fabsf(a); }
 // mask = 2 * mask + (the sign bit of x): one v_alignbit_b32.
 RT_FN uint32_t push_sign(uint32_t mask, float x) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(x), 31u); }
 #else
@@ -149,6 +150,7 @@ RT_FN uint32_t f2u(float f)
   return u;
 }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
+RT_FN float hw_abs(float a) { return fabsf(a); }
 RT_FN uint32_t push_sign(uint32_t mask, float x) { return (mask << 1) | (f2u(x) >> 31); }
 #endif
 
@@ -223,7 +225,10 @@ struct TraceArgs
 {
   // scene, device memory
   const f4 * spheres;          // n_padded x (cx, cy, cz, r*r): what the exact intersection reads
-  const f4 * filter;           // n_padded x (cx, cy, cz, radius widened by the filter margin)
+  const f4 * filter;           // n_padded x (cx, cy, cz, square of the radius widened by the filter margin)
+  const float * aux_rw;        // n_padded x the widened radius itself: what a shadow-cone test adds per sphere ...
+  const float * aux_cone;      // ... and, for kernels specialised for one light, the whole sphere-dependent part of
+                               // that test, dot(centre, cone axis) + cone sin * widened radius (see filter_sphere_2)
   const f4 * camtab;           // n_padded x (centre - camera, filter bound): the primary-ray filter
   const uint32_t * sphere_mat; // n_spheres
   const f4 * materials;        // n_materials x RT_MAT_RECORDS: (albedo rgb, roughness), (refraction, type bits,
@@ -322,10 +327,9 @@ struct LaneCounters
 // dot(d, D) >= sqrt(c), c = |d|^2 - r^2.  The bound is taken from c - m (|d|^2 + r^2), m = RT_FILTER_MARGIN
 // (the filter records hold the radius widened to rw >= r (1 + m), so rw^2 >= r^2 (1 + m)), so that rounding
 // here (FMAs, approximate sqrt: a few ulps of |d|^2) can never reject a ray the exact intersection would
-// accept; an origin on or inside the widened sphere gives bound 0.
-RT_FN float filter_bound(float dx, float dy, float dz, float rw)
+// accept; an origin on or inside the widened sphere gives bound 0.  r2f: the square of the widened radius.
+RT_FN float filter_bound(float dx, float dy, float dz, float r2f)
 {
-  float const r2f = rw * rw;
   float const dd = hw_fma(dz, dz, hw_fma(dy, dy, dx * dx));
   // sqrt of a negative number is a NaN, which max() turns into the 0 wanted for an origin inside the sphere
   return hw_max(hw_sqrt(hw_fma(dd, (float)(1.0 - RT_FILTER_MARGIN), -r2f)), 0.0f);
@@ -732,21 +736,38 @@ struct ShadowCone
 {
   f3 axis;
   float cos_m, sin_m;
+  float cos2_m;  // cos_m^2
+  float oa;      // one-light kernels: dot(origin of the pass, axis), lowered by its own rounding error
 };
 
-// One sphere against the shadow cone and the scattered ray of a pass (common origin o).
-RT_FN void filter_sphere_2(f4 s, f3 o, const ShadowCone & cone, f3 sdir, uint32_t & cone_mask, uint32_t & ray_mask)
+// One sphere against the shadow cone and the scattered ray of a pass (common origin o).  Both tests are taken in
+// squared form, so that no square root is needed per sphere: with b2 = |d|^2 (1 - m) - rw^2, the square of
+// filter_bound's value (negative for an origin inside the widened sphere, where filter_bound gives 0),
+//   ray   u = dot(d, D) >= sqrt(b2)                  <=>  u >= 0 and u^2 >= b2           <=>  u |u| - b2 >= 0
+//   cone  s = dot(d, axis) + sin rw >= cos sqrt(b2)  <=>  s >= 0 and s^2 >= cos^2 b2     <=>  s |s| - cos^2 b2 >= 0
+// (for b2 < 0 the right-hand forms accept a little more than u >= 0 and s >= 0: the safe side).  Squaring costs a
+// rounding of a few 1e-8 of |d|^2, which the margin m covers many times over.
+// s.w holds rw^2.  aux: rw, or -- kKnownCone, kernels whose one light is known when the scene is made -- the part
+// of s that depends on the sphere alone, dot(C, axis) + sin rw, raised by the rounding error it and the
+// subtraction below can have (rt_prep.h cone_constant); s is then one subtraction from cone.oa = dot(o, axis).
+template <bool kKnownCone>
+RT_FN void filter_sphere_2(f4 s, float aux, f3 o, const ShadowCone & cone, f3 sdir, uint32_t & cone_mask,
+                           uint32_t & ray_mask)
 {
   float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
-  float const bound = filter_bound(dx, dy, dz, s.w);
-  float const nb_cone = hw_fma(cone.sin_m, s.w, -(cone.cos_m * bound));
-  cone_mask = push_sign(cone_mask, hw_fma(dz, cone.axis.z, hw_fma(dy, cone.axis.y, hw_fma(dx, cone.axis.x, nb_cone))));
-  ray_mask = push_sign(ray_mask, hw_fma(dz, sdir.z, hw_fma(dy, sdir.y, hw_fma(dx, sdir.x, -bound))));
+  float const dd = hw_fma(dz, dz, hw_fma(dy, dy, dx * dx));
+  float const nb2 = hw_fma(dd, -(float)(1.0 - RT_FILTER_MARGIN), s.w);  // -b2
+  float const u = hw_fma(dz, sdir.z, hw_fma(dy, sdir.y, dx * sdir.x));
+  ray_mask = push_sign(ray_mask, hw_fma(u, hw_abs(u), nb2));
+  float const sc = kKnownCone
+                       ? aux - cone.oa
+                       : hw_fma(dz, cone.axis.z, hw_fma(dy, cone.axis.y, hw_fma(dx, cone.axis.x, cone.sin_m * aux)));
+  cone_mask = push_sign(cone_mask, hw_fma(sc, hw_abs(sc), cone.cos2_m * nb2));
 }
 
 // The shadow cone and the scattered ray against `count` (<= RT_CHUNK) spheres.
-template <uint32_t kUnroll>
-RT_FN void filter_chunk_2(const f4 * sph, uint32_t count, f3 o, const ShadowCone & cone, f3 sdir,
+template <uint32_t kUnroll, bool kKnownCone>
+RT_FN void filter_chunk_2(const f4 * sph, const float * aux, uint32_t count, f3 o, const ShadowCone & cone, f3 sdir,
                           uint32_t & cone_mask, uint32_t & ray_mask)
 {
   cone_mask = 0;
@@ -756,10 +777,10 @@ RT_FN void filter_chunk_2(const f4 * sph, uint32_t count, f3 o, const ShadowCone
   {
 #pragma unroll
     for (uint32_t u = 0; u < kUnroll; ++u)
-      filter_sphere_2(sph[j + u], o, cone, sdir, cone_mask, ray_mask);
+      filter_sphere_2<kKnownCone>(sph[j + u], aux[j + u], o, cone, sdir, cone_mask, ray_mask);
   }
   for (; j < count; ++j)
-    filter_sphere_2(sph[j], o, cone, sdir, cone_mask, ray_mask);
+    filter_sphere_2<kKnownCone>(sph[j], aux[j], o, cone, sdir, cone_mask, ray_mask);
   cone_mask = chunk_candidates(cone_mask, count);
   ray_mask = chunk_candidates(ray_mask, count);
 }
@@ -815,7 +836,8 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //                     light(l, k): record k of material m / light l;  jitter_table()
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
-//                     tile_data(primary)
+//                     tile_data(primary);  tile_aux(): the per-sphere cone term of the staged filter records
+//                     (TraceArgs::aux_cone for a kernel specialised for one light, else TraceArgs::aux_rw)
 // One axis of a walk through the uniform grid: the cell coordinate and the ray parameter at the next wall.
 struct GridAxis
 {
@@ -1030,7 +1052,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
 
 // rays_on: bit r set if ray r of this lane is to be traced.  Returns the shadow rays found occluded as bits
 // 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.  `cone` holds dir[0..4].
-template <bool kGrid, class Env>
+template <bool kGrid, bool kOneLight, class Env>
 RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
                           const ShadowCone & cone, uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
 {
@@ -1059,6 +1081,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
     uint32_t const tile_count = env.load_tile(k, false);
     uint32_t const tile_base = env.tile_base(k);
     const f4 * sph = env.tile_data(false);
+    const float * aux = env.tile_aux();
     // The filter runs chunk by chunk (one 32-bit mask per test), the candidates are resolved per group of two
     // chunks: the loops below go round as often as the lane of the wave with the most candidates needs, so one
     // loop over 64 spheres takes fewer trips than two loops over 32.
@@ -1069,9 +1092,10 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       uint32_t const count_hi = (rest < RT_CHUNK) ? rest : RT_CHUNK;
       uint32_t cone_lo, ray_lo, cone_hi = 0u, ray_hi = 0u;
       RT_REGION(cnt, 6);
-      filter_chunk_2<Env::kFilterUnroll>(sph + c0, count_lo, o, cone, dir[RT_RAYS - 1], cone_lo, ray_lo);
+      filter_chunk_2<Env::kFilterUnroll, kOneLight>(sph + c0, aux + c0, count_lo, o, cone, dir[RT_RAYS - 1], cone_lo, ray_lo);
       if (count_hi != 0u)
-        filter_chunk_2<Env::kFilterUnroll>(sph + c0 + RT_CHUNK, count_hi, o, cone, dir[RT_RAYS - 1], cone_hi, ray_hi);
+        filter_chunk_2<Env::kFilterUnroll, kOneLight>(sph + c0 + RT_CHUNK, aux + c0 + RT_CHUNK, count_hi, o, cone,
+                                                      dir[RT_RAYS - 1], cone_hi, ray_hi);
       RT_REGION(cnt, 7);
       // sphere j of the group in bit 63 - j: the lowest index is the highest bit
       unsigned long long cone_mask = group_mask(cone_lo, count_lo, cone_hi, count_hi);
@@ -1438,10 +1462,19 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       rays_on |= (in_pass && L.li == 0u) ? (1u << (RT_RAYS - 1)) : 0u;
     }
 
+    cone.cos2_m = cone.cos_m * cone.cos_m;
+    cone.oa = 0.0f;
+    if constexpr (kOneLight)
+    {
+      // dot(hit point, axis), lowered by four times the rounding error its three operations can have
+      float const l1 = hw_fma(hw_abs(L.hp.z), hw_abs(cone.axis.z),
+                              hw_fma(hw_abs(L.hp.y), hw_abs(cone.axis.y), hw_abs(L.hp.x) * hw_abs(cone.axis.x)));
+      cone.oa = hw_fma(-4e-7f, l1, fdot3(L.hp, cone.axis));
+    }
     float near_t;
     int near_i;
     RT_REGION(cnt, 9);
-    uint32_t const occluded = trace_pass<kGrid>(A, env, L.hp, dir, a, cone, rays_on, near_t, near_i, cnt);
+    uint32_t const occluded = trace_pass<kGrid, kOneLight>(A, env, L.hp, dir, a, cone, rays_on, near_t, near_i, cnt);
 
     if (in_pass)
     {

@@ -264,6 +264,7 @@ struct WaveEnv
   const f4 * mats;       // LDS: 2 * n_materials
   const f4 * lights;     // LDS: RT_LIGHT_RECORDS * n_lights
   const uint32_t * smat; // LDS: n_padded material indices
+  const float * aux;     // LDS: n_padded cone terms (aux_cone for the one-light kernels, else aux_rw)
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ColumnEntry * batch;   // LDS: this wave's kItemBatch prepared columns (column masks only)
   ItemPool pool;
@@ -283,6 +284,7 @@ struct WaveEnv
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return A.n_padded; }
   __device__ __forceinline__ const f4 * tile_data(bool primary) const { return primary ? cam : filt; }
+  __device__ __forceinline__ const float * tile_aux() const { return aux; }
 
   // With column masks the wave prepares a whole window when it opens one: lane l sets up the column at queue
   // position base + l (ray set-up and candidate masks, one filter pass per column instead of one per sample)
@@ -350,6 +352,8 @@ struct BlockEnv
   static constexpr uint32_t kFilterUnroll = RT_BLOCK_UNROLL;  // almost all of this path's time is the filter
   const TraceArgs & A;
   f4 * tile;              // LDS: kTileSpheres entries
+  float * tile_cone;      // LDS: kTileSpheres cone terms, staged with the filter records
+  const float * aux_src;  // where those come from: A.aux_cone for the one-light kernel, else A.aux_rw
   const float * jitter;   // LDS: RT_JITTER_FLOATS
   ItemPool pool;
 
@@ -380,10 +384,14 @@ struct BlockEnv
     __syncthreads();  // everyone is done with the previous tile
     for (uint32_t i = threadIdx.x; i < count; i += kBlock)
       tile[i] = src[i];
+    if (!primary)
+      for (uint32_t i = threadIdx.x; i < count; i += kBlock)
+        tile_cone[i] = aux_src[base + i];
     __syncthreads();
     return count;
   }
   __device__ __forceinline__ const f4 * tile_data(bool) const { return tile; }
+  __device__ __forceinline__ const float * tile_aux() const { return tile_cone; }
 };
 
 // Grid walks: every ray finds its own spheres, read from global memory (the L2 holds the scene); waves never
@@ -416,6 +424,7 @@ struct GridEnv
   __device__ __forceinline__ uint32_t tile_base(uint32_t) const { return 0u; }
   __device__ __forceinline__ uint32_t load_tile(uint32_t, bool) const { return 0u; }
   __device__ __forceinline__ const f4 * tile_data(bool) const { return nullptr; }
+  __device__ __forceinline__ const float * tile_aux() const { return nullptr; }
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(uint32_t lane_value)
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   if constexpr (kTiled)
   {
     __syncthreads();
-    BlockEnv env{A, sph, jitter, ItemPool()};
+    BlockEnv env{A, sph, reinterpret_cast<float *>(sph + kTileSpheres), kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
@@ -494,7 +503,8 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     f4 * mats = exact + A.n_padded;
     f4 * lights = mats + RT_MAT_RECORDS * A.n_materials;
     uint32_t * smat = reinterpret_cast<uint32_t *>(lights + RT_LIGHT_RECORDS * A.n_lights);
-    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(smat + ((A.n_padded + 3u) & ~3u));
+    float * aux = reinterpret_cast<float *>(smat + ((A.n_padded + 3u) & ~3u));
+    ColumnEntry * batch = reinterpret_cast<ColumnEntry *>(aux + ((A.n_padded + 3u) & ~3u));
     for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
     {
       sph[i] = A.filter[i];
@@ -506,12 +516,15 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     for (uint32_t i = threadIdx.x; i < RT_LIGHT_RECORDS * A.n_lights; i += kBlock)
       lights[i] = A.lights[i];
     for (uint32_t i = threadIdx.x; i < A.n_padded; i += kBlock)
+    {
       smat[i] = A.sphere_mat[i];
+      aux[i] = kOneLight ? A.aux_cone[i] : A.aux_rw[i];
+    }
     __syncthreads();
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
-    WaveEnv env{A, sph, cam, exact, mats, lights, smat, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
+    WaveEnv env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
@@ -775,6 +788,8 @@ struct rt_hip_scene
 {
   f4 * d_spheres = nullptr;  // exact records, n_padded
   f4 * d_filter = nullptr;   // filter records, n_padded
+  float * d_aux_rw = nullptr;    // per sphere, the cone term of a shade pass: for any light ...
+  float * d_aux_cone = nullptr;  // ... and for light 0 alone (TraceArgs::aux_rw, aux_cone)
   uint32_t * d_sphere_mat = nullptr;
   f4 * d_materials = nullptr;
   f4 * d_lights = nullptr;
@@ -847,12 +862,12 @@ bool share_disabled() { return std::getenv("RT_HIP_NO_SHARING") != nullptr; }
 bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }
 
 // LDS of the resident layout: path stacks (scenes whose paths cannot be accumulated forward), the jitter table,
-// three records and a material index per sphere, the materials and lights, one prepared-column table per wave.
+// three records, a material index and a cone term per sphere, the materials and lights, one prepared-column table per wave.
 size_t resident_lds_bytes(const rt_hip_scene * sc)
 {
   return (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS +
          sizeof(f4) * (size_t)(3u * sc->n_padded + RT_MAT_RECORDS * sc->n_materials + RT_LIGHT_RECORDS * sc->n_lights) +
-         sizeof(uint32_t) * (size_t)((sc->n_padded + 3u) & ~3u) + sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
+         (sizeof(uint32_t) + sizeof(float)) * (size_t)((sc->n_padded + 3u) & ~3u) + sizeof(ColumnEntry) * (size_t)(kBlock / 64) * kItemBatch;
 }
 
 // A scene is staged through LDS in tiles when it is too large to live there whole: too many records for the
@@ -876,7 +891,7 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
   if (uses_grid(sc, flags))
     return bytes;
   if (is_tiled(sc))
-    bytes += sizeof(f4) * (size_t)kTileSpheres;
+    bytes += (sizeof(f4) + sizeof(float)) * (size_t)kTileSpheres;
   else
     bytes = resident_lds_bytes(sc);
   return std::max<size_t>(bytes, 16u);
@@ -1024,6 +1039,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   prepare_frame(*camera, *p, a);
   a.spheres = scene->d_spheres;
   a.filter = scene->d_filter;
+  a.aux_rw = scene->d_aux_rw;
+  a.aux_cone = scene->d_aux_cone;
   a.camtab = d_camtab;
   a.sphere_mat = scene->d_sphere_mat;
   a.materials = scene->d_materials;
@@ -1105,7 +1122,11 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   return RT_HIP_OK;
 }
 
-int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream)
+// beside_trace: the pass is a snapshot's and has to run in the block slots a running trace kernel leaves free.
+// Measured on a 3840x2160 job: the lane-per-pixel kernel does (12 ms per snapshot), the LDS kernel, 50 KB a block,
+// waits for the frame's end.
+int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream,
+                  bool beside_trace = false)
 {
   uint32_t const n = p->width * p->height;
   // the sample counts of the reference's demos and of the benchmark go through LDS (whole-line loads)
@@ -1114,7 +1135,7 @@ int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_
     int const blocks = (int)std::min<uint32_t>((groups + 3u) / 4u, 256u * 3u);
     hipLaunchKernelGGL(kernel, dim3(std::max(blocks, 1)), dim3(256), 0, stream, d_partial, d_planes, n);
   };
-  switch (std::getenv("RT_HIP_PLAIN_COLSUM") ? 0u : p->samples_in_row)
+  switch ((beside_trace || std::getenv("RT_HIP_PLAIN_COLSUM")) ? 0u : p->samples_in_row)
   {
   case 2: through_lds(colsum_lds_kernel<2, 64>, 64u); break;
   case 4: through_lds(colsum_lds_kernel<4, 64>, 64u); break;
@@ -1423,6 +1444,10 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   if (e == hipSuccess)
     e = upload((void **)&s->d_filter, fs.filter.data(), fs.filter.size() * sizeof(f4));
   if (e == hipSuccess)
+    e = upload((void **)&s->d_aux_rw, fs.aux_rw.data(), fs.aux_rw.size() * sizeof(float));
+  if (e == hipSuccess)
+    e = upload((void **)&s->d_aux_cone, fs.aux_cone.data(), fs.aux_cone.size() * sizeof(float));
+  if (e == hipSuccess)
     e = upload((void **)&s->d_sphere_mat, fs.sphere_mat.data(), fs.sphere_mat.size() * sizeof(uint32_t));
   if (e == hipSuccess)
     e = upload((void **)&s->d_materials, fs.materials.data(), fs.materials.size() * sizeof(f4));
@@ -1464,6 +1489,8 @@ void rt_hip_scene_destroy(rt_hip_scene * scene)
     return;
   if (scene->d_spheres) (void)hipFree(scene->d_spheres);
   if (scene->d_filter) (void)hipFree(scene->d_filter);
+  if (scene->d_aux_rw) (void)hipFree(scene->d_aux_rw);
+  if (scene->d_aux_cone) (void)hipFree(scene->d_aux_cone);
   if (scene->d_sphere_mat) (void)hipFree(scene->d_sphere_mat);
   if (scene->d_materials) (void)hipFree(scene->d_materials);
   if (scene->d_lights) (void)hipFree(scene->d_lights);
@@ -1551,7 +1578,7 @@ int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
   }
   // Accumulate, resolve and download on the copy stream: they run beside the trace kernel and never wait for it.
   // Columns the trace has not finished yet still hold the zeros they were cleared to.
-  int rc = launch_colsum(job->d_partial, job->d_snap_planes, &job->params, g_lib.copy_stream);
+  int rc = launch_colsum(job->d_partial, job->d_snap_planes, &job->params, g_lib.copy_stream, true);
   if (rc == RT_HIP_OK)
     rc = launch_resolve(job->d_snap_planes, job->d_snap_rgb, job->params.width, job->params.height,
                         job->params.samples_in_row, g_lib.copy_stream);

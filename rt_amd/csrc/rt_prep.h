@@ -224,7 +224,9 @@ inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
 struct FlatScene
 {
   std::vector<f4> spheres;           // (cx, cy, cz, r*r)
-  std::vector<f4> filter;            // (cx, cy, cz, radius widened by the filter margin)
+  std::vector<f4> filter;            // (cx, cy, cz, square of the radius widened by the filter margin)
+  std::vector<float> aux_rw;         // the widened radius
+  std::vector<float> aux_cone;       // cone_constant of the sphere for the first light's shadow cone
   std::vector<uint32_t> sphere_mat;  // material index per sphere
   std::vector<f4> materials;         // RT_MAT_RECORDS per material
   std::vector<f4> lights;            // RT_LIGHT_RECORDS per light
@@ -241,6 +243,8 @@ inline ShadowCone shadow_cone(const float * light_direction, bool use_cone)
   c.axis = mk3(0.0f, 1.0f, 0.0f);
   c.cos_m = 0.0f;
   c.sin_m = 3.0e38f;
+  c.cos2_m = 0.0f;
+  c.oa = 0.0f;
   if (light_direction == nullptr)
     return c;
   double const x = light_direction[0], y = light_direction[1], z = light_direction[2];
@@ -254,7 +258,23 @@ inline ShadowCone shadow_cone(const float * light_direction, bool use_cone)
   double const sin_m = sin_t * 1.001 + 1e-4;
   c.sin_m = (float)sin_m;
   c.cos_m = (float)(std::sqrt(1.0 - sin_m * sin_m) * 0.999);
+  c.cos2_m = c.cos_m * c.cos_m;
   return c;
+}
+
+// The part of a shadow-cone test that depends on the sphere alone (rt_core.h filter_sphere_2): dot(C, axis) +
+// sin_m rw.  The kernel subtracts dot(O, axis) from it in float, so the value is raised by more than the rounding
+// errors of storing it and of that subtraction (each at most 6e-8 of the terms' magnitudes): the test stays on
+// the accepting side.  The cone that holds every direction gets a value no subtraction brings below zero.
+inline float cone_constant(const float * centre, float rw, const ShadowCone & cone)
+{
+  if (!(cone.sin_m < 1e30f))
+    return 3.0e38f;
+  double const tx = (double)centre[0] * cone.axis.x, ty = (double)centre[1] * cone.axis.y, tz = (double)centre[2] * cone.axis.z;
+  double const tr = (double)cone.sin_m * rw;
+  double const k = tx + ty + tz + tr;
+  double const raised = k + 4e-7 * (std::fabs(tx) + std::fabs(ty) + std::fabs(tz) + tr);
+  return std::nextafter(static_cast<float>(raised), INFINITY);
 }
 
 RT_HD f4 mk4(float x, float y, float z, float w)
@@ -275,15 +295,22 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
 {
   out.spheres.resize(n);
   out.filter.resize(n);
+  out.aux_rw.resize(n);
+  out.aux_cone.resize(n);
+  ShadowCone const cone0 = shadow_cone(l != 0u ? lights[0].direction : nullptr, shadow_cones);
   out.sphere_mat.assign(material_index, material_index + n);
   for (uint32_t i = 0; i < n; ++i)
   {
     const float * s = centers_radii + 4u * i;
     float const r2 = s[3] * s[3];  // m_radius * m_radius, sphere.cpp:68
     out.spheres[i] = mk4(s[0], s[1], s[2], r2);
-    // the widened radius: its float square is at least r^2 (1 + m) whatever way the product rounds
+    // the widened radius, rounded up, and its square, rounded up
     double const widened = std::fabs(static_cast<double>(s[3])) * (1.0 + RT_FILTER_MARGIN);
-    out.filter[i] = mk4(s[0], s[1], s[2], std::max(std::nextafter(static_cast<float>(widened), INFINITY), 1e-30f));
+    float const rw = std::max(std::nextafter(static_cast<float>(widened), INFINITY), 1e-30f);
+    float const rw2 = std::nextafter(static_cast<float>((double)rw * rw), INFINITY);
+    out.filter[i] = mk4(s[0], s[1], s[2], rw2);
+    out.aux_rw[i] = rw;
+    out.aux_cone[i] = cone_constant(s, rw, cone0);
   }
   // Per-material constants of Scatter and GetSpecular, computed here once with the float operations the
   // reference uses per hit (ray_tracing/default_materials.cpp:30,50,61-62; directional_light.cpp:49-56).

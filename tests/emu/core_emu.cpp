@@ -17,6 +17,8 @@ struct HostEnv
   uint32_t next = 0;
   uint32_t cur_count = 0;
   const rtc::f4 * cur = nullptr;
+  const float * aux_src = nullptr;  // A.aux_cone when the loop is the one specialised for one light, else A.aux_rw
+  const float * cur_aux = nullptr;
 
   // Sample-sharing test mode.  The kernel shares samples between the lanes of a wave once its queue is used
   // up; this one-lane build exercises the same bookkeeping (shortened columns, shared-sample entries, split
@@ -92,10 +94,12 @@ struct HostEnv
   {
     uint32_t const base = k * tile_size;
     cur = (primary ? A.camtab : A.filter) + base;
+    cur_aux = aux_src + base;
     cur_count = (A.n_padded - base < tile_size) ? (A.n_padded - base) : tile_size;
     return cur_count;
   }
   const rtc::f4 * tile_data(bool) const { return cur; }
+  const float * tile_aux() const { return cur_aux; }
 };
 }  // namespace
 
@@ -157,6 +161,8 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   a.jitter_tab = jitter.data();
   a.spheres = fs.spheres.data();
   a.filter = fs.filter.data();
+  a.aux_rw = fs.aux_rw.data();
+  a.aux_cone = fs.aux_cone.data();
   a.camtab = camtab.data();
   a.n_padded = padded;
   a.sphere_mat = fs.sphere_mat.data();
@@ -191,6 +197,8 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   // the forward-accumulating loop comes specialised for one light, as in the library (mode bit 4 keeps the
   // general loop for such scenes)
   bool const one_light = l == 1u && (mode & 16u) == 0u;
+  // (only the forward-accumulating loops come specialised for one light)
+  env.aux_src = (one_light && (mode & 2u) != 0u) ? a.aux_cone : a.aux_rw;
   rtc::GridHost grid;
   if ((mode & 4u) != 0u)
   {

@@ -21,25 +21,29 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = ffi.HipRenderer(0)
 
 
-def random_scene(k):
+def random_scene(k, offset=(0.0, 0.0, 0.0)):
     """A few dozen spheres of all materials under one to three lights whose directions are not normalised (the
-    shadow cone's opening depends on the light vector's length; a short one has no cone at all)."""
+    shadow cone's opening depends on the light vector's length; a short one has no cone at all).  offset moves
+    the whole scene and the camera away from the origin: the filter's per-sphere constants are taken in world
+    coordinates and must stay on the safe side where those are large against the spheres."""
     g = np.random.default_rng(1000 + k)
+    ox, oy, oz = offset
     mats = [(0, (0.6, 0.6, 0.6), 0.7, 0.0)]
-    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0)]
+    spheres = [(ox, oy - 1001.0, oz, 1000.0, 0)]
     for _ in range(int(g.integers(5, 60))):
         kind = int(g.integers(0, 3))
         mats.append((kind, tuple(float(x) for x in g.uniform(0.1, 1.0, 3)), float(g.uniform(0.0, 0.9)) if kind == 1 else 0.7,
                      float(g.uniform(0.8, 0.9)) if kind == 2 else float(g.uniform(0.0, 0.2))))
         rad = float(g.uniform(0.15, 0.6))
-        spheres.append((float(g.uniform(-4, 4)), rad - 1.0 + float(g.uniform(0, 1.5)), float(g.uniform(0, 8)), rad, len(mats) - 1))
+        spheres.append((ox + float(g.uniform(-4, 4)), oy + rad - 1.0 + float(g.uniform(0, 1.5)), oz + float(g.uniform(0, 8)), rad,
+                        len(mats) - 1))
     lights = []
     for _ in range(int(g.integers(1, 4))):
         d = g.normal(size=3)
         d[1] = -abs(d[1]) - 0.3
         d *= float(g.choice([0.2, 0.27, 0.5, 1.0, 1.0, 3.0])) / np.linalg.norm(d)
         lights.append((tuple(float(x) for x in d), tuple(float(x) for x in g.uniform(0.2, 1.0, 3))))
-    return ffi.Scene.build(spheres, mats, lights, dict(position=(0.0, 0.8, -4.0), direction=(0.0, -0.15, 1.0),
+    return ffi.Scene.build(spheres, mats, lights, dict(position=(ox + 0.0, oy + 0.8, oz - 4.0), direction=(0.0, -0.15, 1.0),
                                                         background=(0.8, 0.85, 0.9)))
 
 
@@ -54,7 +58,9 @@ def without_cones(make):
 
 
 makers = [lambda: ffi.Scene.demo(1, 1), lambda: ffi.Scene.demo(2, 1), lambda: ffi.Scene.demo(3, 1, 100),
-          lambda: ffi.Scene.demo(3, 1, 700)] + [(lambda k=k: random_scene(k)) for k in range(8)]
+          lambda: ffi.Scene.demo(3, 1, 700)] + [(lambda k=k: random_scene(k)) for k in range(8)] + [
+    (lambda k=k, o=o: random_scene(k, o)) for k, o in ((8, (30.0, -20.0, 50.0)), (9, (-300.0, 200.0, 100.0)), (10, (1000.0, 3000.0, -2000.0)),
+                                                       (11, (-2e4, 1e4, 3e4)))]
 scenes = [m() for m in makers]
 plain = [without_cones(m) for m in makers]
 cases = worst = 0

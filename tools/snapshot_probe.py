@@ -3,7 +3,7 @@
 Starts a 1080p 16x16 glass_spheres job, takes one snapshot right away and reports how long the snapshot took,
 whether the job was still running afterwards and what share of the pixels was still unfinished in it.
 
-python tools/snapshot_probe.py
+python tools/snapshot_probe.py [WIDTH HEIGHT SAMPLES_IN_ROW]
 """
 import os
 import sys
@@ -14,7 +14,8 @@ from rt_amd import ffi  # noqa: E402
 
 r = ffi.HipRenderer(0)
 sc = ffi.Scene.demo(2, 1)
-p = ffi.params(1920, 1080, 16, seed=3)
+w, h, s_row = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1920, 1080, 16)
+p = ffi.params(w, h, s_row, seed=3)
 r.render(sc, p)  # warm-up
 for _ in range(2):
     t0 = time.perf_counter()
