@@ -241,6 +241,7 @@ struct TraceArgs
   uint32_t tile_size;          // filter records staged per tile when the scene is not resident
   f3 cone_axis;                // ShadowCone of light 0, for kernels specialised for one light (wave-uniform there)
   float cone_cos, cone_sin;
+  float cone_inv_cos;          // 1 / cone_cos (1 for the cone that holds every direction)
   // camera, precomputed on the host exactly as Frame::ForEachRayImpl does (ray_tracing/frame.cpp:33-41)
   f3 cam_pos, cam_dir, cam_right, cam_up, background;
   float znear, zfar, dw, dh, cell_x, cell_y;
@@ -737,7 +738,7 @@ struct ShadowCone
   f3 axis;
   float cos_m, sin_m;
   float cos2_m;  // cos_m^2
-  float oa;      // one-light kernels: dot(origin of the pass, axis), lowered by its own rounding error
+  float oa;      // one-light kernels: dot(origin of the pass, axis) / cos_m, lowered by its own rounding error
 };
 
 // One sphere against the shadow cone and the scattered ray of a pass (common origin o).  Both tests are taken in
@@ -748,8 +749,9 @@ struct ShadowCone
 // (for b2 < 0 the right-hand forms accept a little more than u >= 0 and s >= 0: the safe side).  Squaring costs a
 // rounding of a few 1e-8 of |d|^2, which the margin m covers many times over.
 // s.w holds rw^2.  aux: rw, or -- kKnownCone, kernels whose one light is known when the scene is made -- the part
-// of s that depends on the sphere alone, dot(C, axis) + sin rw, raised by the rounding error it and the
-// subtraction below can have (rt_prep.h cone_constant); s is then one subtraction from cone.oa = dot(o, axis).
+// of s / cos that depends on the sphere alone, (dot(C, axis) + sin rw) / cos, raised by the rounding error it and
+// the subtraction below can have (rt_prep.h cone_constant); s / cos is then one subtraction, of cone.oa =
+// dot(o, axis) / cos, and the test reads (s / cos) |s / cos| - b2 >= 0.
 template <bool kKnownCone>
 RT_FN void filter_sphere_2(f4 s, float aux, f3 o, const ShadowCone & cone, f3 sdir, uint32_t & cone_mask,
                            uint32_t & ray_mask)
@@ -759,10 +761,16 @@ RT_FN void filter_sphere_2(f4 s, float aux, f3 o, const ShadowCone & cone, f3 sd
   float const nb2 = hw_fma(dd, -(float)(1.0 - RT_FILTER_MARGIN), s.w);  // -b2
   float const u = hw_fma(dz, sdir.z, hw_fma(dy, sdir.y, dx * sdir.x));
   ray_mask = push_sign(ray_mask, hw_fma(u, hw_abs(u), nb2));
-  float const sc = kKnownCone
-                       ? aux - cone.oa
-                       : hw_fma(dz, cone.axis.z, hw_fma(dy, cone.axis.y, hw_fma(dx, cone.axis.x, cone.sin_m * aux)));
-  cone_mask = push_sign(cone_mask, hw_fma(sc, hw_abs(sc), cone.cos2_m * nb2));
+  if constexpr (kKnownCone)
+  {
+    float const sc = aux - cone.oa;
+    cone_mask = push_sign(cone_mask, hw_fma(sc, hw_abs(sc), nb2));
+  }
+  else
+  {
+    float const sc = hw_fma(dz, cone.axis.z, hw_fma(dy, cone.axis.y, hw_fma(dx, cone.axis.x, cone.sin_m * aux)));
+    cone_mask = push_sign(cone_mask, hw_fma(sc, hw_abs(sc), cone.cos2_m * nb2));
+  }
 }
 
 // The shadow cone and the scattered ray against `count` (<= RT_CHUNK) spheres.
@@ -1466,10 +1474,11 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     cone.oa = 0.0f;
     if constexpr (kOneLight)
     {
-      // dot(hit point, axis), lowered by four times the rounding error its three operations can have
+      // dot(hit point, axis) / cos, lowered by several times the rounding error its operations can have (three
+      // for the dot product, the rounding of 1 / cos and the last multiplication: 6e-8 of the terms' sizes each)
       float const l1 = hw_fma(hw_abs(L.hp.z), hw_abs(cone.axis.z),
                               hw_fma(hw_abs(L.hp.y), hw_abs(cone.axis.y), hw_abs(L.hp.x) * hw_abs(cone.axis.x)));
-      cone.oa = hw_fma(-4e-7f, l1, fdot3(L.hp, cone.axis));
+      cone.oa = hw_fma(-8e-7f, l1, fdot3(L.hp, cone.axis)) * A.cone_inv_cos;
     }
     float near_t;
     int near_i;

@@ -42,7 +42,7 @@ using namespace rtc;
 
 // Tuning knobs an experiment build may override (-D...); the values here are the measured best.
 #ifndef RT_WAVE_UNROLL
-#define RT_WAVE_UNROLL 2
+#define RT_WAVE_UNROLL 4
 #endif
 #ifndef RT_BLOCK_UNROLL
 #define RT_BLOCK_UNROLL 4
@@ -921,8 +921,16 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
 }
 
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
-// more lanes than work items.
-int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long long items, bool leave_room)
+// more lanes than work items -- and fewer for small frames.  A lane traces its samples one after the other, a path
+// of ten bounces is ten trips round the loop, and a trip takes as long as the waves that share the SIMD make it
+// (13 us with four of them, 4 us for a wave on its own).  Where a full grid leaves a lane only a few dozen
+// samples, the frame takes as long as its longest chain of trips, not as long as its work: fewer, faster waves
+// win.  kSamplesPerLane is the measured break-even (41 spheres: 1024x768 2x2 0.72 -> 0.58 ms, 720x540 2x2 0.63 ->
+// 0.41 ms, 1920x1080 2x2 1.04 -> 1.00 ms); never below one wave per SIMD.  Tiled scenes keep the full grid: their
+// blocks move in step and the samples cost a hundred times as much.
+constexpr unsigned long long kSamplesPerLane = 36;
+int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long long items, unsigned long long samples,
+                      bool leave_room)
 {
   size_t const lds = lds_bytes(sc, flags);
   rt_hip_scene::Occupancy & cached = sc->occupancy[uses_grid(sc, flags) ? 1 : 0];
@@ -942,6 +950,14 @@ int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long lon
     blocks -= kSnapshotReserveBlocks;
   long long const needed = ((long long)items + kBlock - 1) / kBlock;
   blocks = std::max(1ll, std::min(blocks, needed));
+  if (!is_tiled(sc) || uses_grid(sc, flags))
+  {
+    long long const one_wave_per_simd = std::max(g_lib.compute_units, 1);
+    long long const wanted = (long long)(samples / (kSamplesPerLane * kBlock));
+    blocks = std::min(blocks, std::max(wanted, one_wave_per_simd));
+  }
+  if (const char * v = std::getenv("RT_HIP_MAX_BLOCKS"))  // experiments: cap on the grid
+    blocks = std::max(1ll, std::min(blocks, (long long)std::strtol(v, nullptr, 10)));
   return (int)blocks;
 }
 
@@ -1054,6 +1070,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.cone_axis = scene->cone0.axis;
   a.cone_cos = scene->cone0.cos_m;
   a.cone_sin = scene->cone0.sin_m;
+  a.cone_inv_cos = scene->cone0.cos_m > 0.0f ? 1.0f / scene->cone0.cos_m : 1.0f;
   a.partial = d_partial;
   a.n_items = p->width * p->height * p->samples_in_row;
   a.stats = want_stats ? d_stats : nullptr;
@@ -1083,7 +1100,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
   bool const leave_room = (p->flags & RT_HIP_FLAG_LEAVE_ROOM) != 0u ||
                           (d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples);
-  int const blocks = persistent_blocks(scene, p->flags, a.n_items, leave_room);
+  int const blocks = persistent_blocks(scene, p->flags, a.n_items, (unsigned long long)a.n_items * a.s_row / a.slice_count,
+                                       leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   size_t const lds = lds_bytes(scene, p->flags);
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.

@@ -262,18 +262,19 @@ inline ShadowCone shadow_cone(const float * light_direction, bool use_cone)
   return c;
 }
 
-// The part of a shadow-cone test that depends on the sphere alone (rt_core.h filter_sphere_2): dot(C, axis) +
-// sin_m rw.  The kernel subtracts dot(O, axis) from it in float, so the value is raised by more than the rounding
-// errors of storing it and of that subtraction (each at most 6e-8 of the terms' magnitudes): the test stays on
-// the accepting side.  The cone that holds every direction gets a value no subtraction brings below zero.
+// The part of a shadow-cone test that depends on the sphere alone (rt_core.h filter_sphere_2): (dot(C, axis) +
+// sin_m rw) / cos_m.  The kernel subtracts dot(O, axis) / cos_m from it in float, so the value is raised by more
+// than the rounding errors of storing it and of that subtraction (each at most 6e-8 of the terms' magnitudes): the
+// test stays on the accepting side.  The cone that holds every direction gets a value no subtraction brings below
+// zero.
 inline float cone_constant(const float * centre, float rw, const ShadowCone & cone)
 {
-  if (!(cone.sin_m < 1e30f))
+  if (!(cone.sin_m < 1e30f) || !(cone.cos_m > 0.0f))
     return 3.0e38f;
   double const tx = (double)centre[0] * cone.axis.x, ty = (double)centre[1] * cone.axis.y, tz = (double)centre[2] * cone.axis.z;
   double const tr = (double)cone.sin_m * rw;
   double const k = tx + ty + tz + tr;
-  double const raised = k + 4e-7 * (std::fabs(tx) + std::fabs(ty) + std::fabs(tz) + tr);
+  double const raised = (k + 4e-7 * (std::fabs(tx) + std::fabs(ty) + std::fabs(tz) + tr)) / cone.cos_m;
   return std::nextafter(static_cast<float>(raised), INFINITY);
 }
 

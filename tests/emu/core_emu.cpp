@@ -143,6 +143,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     a.cone_axis = rtc::mk3(fs.lights[2].x, fs.lights[2].y, fs.lights[2].z);
     a.cone_cos = fs.lights[0].w;
     a.cone_sin = fs.lights[1].w;
+    a.cone_inv_cos = a.cone_cos > 0.0f ? 1.0f / a.cone_cos : 1.0f;
   }
   uint32_t const padded = static_cast<uint32_t>(fs.filter.size());
   bool const column_masks = (mode & 1u) != 0u && padded > 0 && padded <= 64;
