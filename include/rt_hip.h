@@ -210,6 +210,14 @@ int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera *
 int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t width, uint32_t height,
                           uint32_t samples_in_row, void * stream);
 
+/* No counterpart in the reference: a self-check of the device arithmetic.  The exact intersections and the
+ * normalisations of the trace kernel take correctly rounded square roots and quotients from sequences shorter
+ * than the compiler's general ones; this runs both on the device the library was initialised on -- every float
+ * for sqrt and for 1 / sqrt, one operand pair per float pattern for the quotient and for the near root of
+ * Sphere::TraceNearest (ray_tracing/sphere.cpp:72-74) -- and reports the number of differing results of each of the
+ * four comparisons (all zero on a device the library supports).  About 0.1 s. */
+int rt_hip_check_exact_math(uint64_t * mismatches4);
+
 /* Average device time (ms) of the trace kernel over `launches` back-to-back launches of the given frame on
  * the library's stream, measured with HIP events on that stream; used by the benchmark's roofline line. */
 int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * camera,

@@ -154,11 +154,84 @@ RT_FN float hw_abs(float a) { return fabsf(a); }
 RT_FN uint32_t push_sign(uint32_t mask, float x) { return (mask << 1) | (f2u(x) >> 31); }
 #endif
 
+// ---- correctly rounded square root and quotient, in fewer instructions than the compiler's general sequences ----
+// The compiler's IEEE sqrtf / division are a hardware estimate, a correction that makes the result correctly
+// rounded, and -- more than a third of their instructions -- scaling and fix-ups for operands near the ends of the
+// float range.  The cores below are those sequences without the scaling: bit-identical results wherever the
+// scaling would not have acted, which the callers establish with one or two instructions for the whole wave and
+// otherwise fall back to the full sequence.  (rt_hip_check_exact_math in rt_hip.hip compares both against the compiler's
+// sequences on the device: every float for the square root and for 1 / sqrt, random and edge-case pairs for the
+// quotient.)
+#if defined(__HIP_DEVICE_COMPILE__)
+// x: zero, +inf, NaN, at most -2^-96 (-> NaN), or finite and at least 2^-96.  The hardware square root is within one ulp;
+// the two neighbours are tried with exact residuals (the compiler's own correction step).
+RT_FN float sqrt_rn_core(float x)
+{
+  float s = __builtin_amdgcn_sqrtf(x);
+  float const s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  float const r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+  s = (r_dn <= 0.0f) ? s_dn : s;
+  s = (r_up > 0.0f) ? s_up : s;
+  return s;
+}
+// n / d for finite operands far from the ends of the float range (|d| in [2^-60, 2^60], |n| in [2^-100, 2^60] or
+// zero, which may come out with the other sign): reciprocal estimate, one Newton step, quotient, two residual
+// corrections -- the compiler's sequence between its scaling and its fix-up.
+RT_FN float div_rn_core(float n, float d)
+{
+  float const r0 = __builtin_amdgcn_rcpf(d);
+  float const e0 = __builtin_fmaf(-d, r0, 1.0f);
+  float const r1 = __builtin_fmaf(e0, r0, r0);
+  float const q0 = n * r1;
+  float const e1 = __builtin_fmaf(-d, q0, n);
+  float const q1 = __builtin_fmaf(e1, r1, q0);
+  float const e2 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(e2, r1, q1);
+}
+// 1 / sqrt(x) as two correctly rounded operations (what v * (1.0f / sqrtf(x)) asks for), x being the squared
+// length of a vector about to be normalised.  The short sequences are exact for 2^-96 <= x < 2^96 (the root lies
+// in [2^-48, 2^48], where 1 / s needs no scaling) and hand a NaN through; for x = 0 they give NaN where the library
+// gives infinity, and the zero vector times either is the same NaN vector.  The vectors
+// the kernel normalises stay in that range when the library has established, for the whole launch (it sets
+// RT_FLAG_LIBRARY_MATH otherwise), that radii, the near plane and the lights' direction vectors are between 2^-40
+// and 2^40 long, roughness at most 2^40 and everything within 2^40 of the origin: a primary direction is at least
+// the near plane long, a normal is hit point - centre (a radius long, or, where the hit point's own rounding
+// exceeds the radius, zero or at least an ulp of coordinates that no hit closer than tmin leaves below 2^-24), and
+// the sums n + ball, reflect + ball * roughness, light + view have a component of at least a half that another
+// float of similar size can only cancel to zero or to 2^-25 or more.
+RT_FN float inv_sqrt_rn(float x, bool library_math)
+{
+  if (library_math)
+    return 1.0f / sqrtf(x);
+  return div_rn_core(1.0f, sqrt_rn_core(x));
+}
+// (-b - sqrt(disc)) / d, the near root of Sphere::TraceNearest (ray_tracing/sphere.cpp:72-74), for lanes whose
+// disc is not negative (the others get some value nobody uses); d = 2 dot(D, D) of a normalised direction, so
+// about 2 (or NaN, which both sequences hand through).  No check of the operands is needed per call when the
+// library has established two things for the whole launch (it launches the kernels built with Env::kLibraryMath otherwise):
+//   - the scene and the camera lie within 2^40 of the origin, so b, disc and the numerator are finite (< 2^90);
+//   - every tmin in use is at least 2^-20.  A discriminant below 2^-96, where sqrt_rn_core may be an ulp off, has a
+//     root below 2^-48, less than half an ulp of any -b that could give t >= tmin: the numerator is -b whatever
+//     that root's last bit.  A numerator below 2^-103, where div_rn_core may be off, gives t < tmin either way.
+// So every distance the caller accepts is the library's, bit for bit, and every rejection is the same rejection.
+RT_FN float near_root(float b, float disc, float d, bool library_math)
+{
+  if (library_math)
+    return (-b - sqrtf(disc)) / d;
+  return div_rn_core(-b - sqrt_rn_core(disc), d);
+}
+#else
+RT_FN float sqrt_rn_core(float x) { return sqrtf(x); }
+RT_FN float div_rn_core(float n, float d) { return n / d; }
+RT_FN float inv_sqrt_rn(float x, bool) { return 1.0f / sqrtf(x); }
+RT_FN float near_root(float b, float disc, float d, bool) { return (-b - sqrtf(disc)) / d; }
+#endif
+
 // ---- exact helpers: the GLSL definitions glm follows, IEEE sqrt and division ----
 RT_FN float minf(float a, float b) { return (b < a) ? b : a; }  // std::min
 RT_FN float maxf(float a, float b) { return (a < b) ? b : a; }  // std::max
 RT_FN float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }
-RT_FN f3 normalize3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+RT_FN f3 normalize3(f3 v, bool library_math) { return v * inv_sqrt_rn(dot3(v, v), library_math); }
 RT_FN float fdot3(f3 a, f3 b) { return hw_fma(a.z, b.z, hw_fma(a.y, b.y, a.x * b.x)); }
 RT_FN f3 normalize3_fast(f3 v) { return v * hw_rsq(dot3(v, v)); }
 RT_FN f3 mix3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
@@ -339,7 +412,7 @@ RT_FN float filter_bound(float dx, float dy, float dz, float r2f)
 // Sphere::TraceNearest, ray_tracing/sphere.cpp:63-81, operation for operation (a = dot(D, D) hoisted).
 // The reference takes min((-b - s) / 2a, (-b + s) / 2a); a > 0 and s >= 0, and IEEE division by a positive
 // number is monotone, so the minimum is always the first quotient, bit for bit.
-RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out)
+RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out, bool library_math)
 {
   f3 const d = o - mk3(s.x, s.y, s.z);
   float const b = 2.0f * dot3(d, dir);
@@ -347,8 +420,7 @@ RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float 
   float const disc = b * b - 4 * a * c;
   if (disc < 0.0f)
     return false;
-  float const sq = sqrtf(disc);
-  float const t = (-b - sq) / (2.0f * a);
+  float const t = near_root(b, disc, 2.0f * a, library_math);
   if (t < tmin || t > tmax)
     return false;
   t_out = t;
@@ -357,7 +429,7 @@ RT_FN bool exact_hit(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float 
 
 // The same test without early exits, for resolving two candidates side by side.  Same operations, same
 // results (a negative discriminant is rejected whatever its square root turns into).
-RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out)
+RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, float & t_out, bool library_math)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
   // Keeps 4a and 2a from being computed ahead of the resolution loops for all six rays (a dozen registers held
@@ -368,8 +440,7 @@ RT_FN bool exact_hit_flat(f3 o, f3 dir, float a, f4 s, float tmin, float tmax, f
   float const b = 2.0f * dot3(d, dir);
   float const c = dot3(d, d) - s.w;
   float const disc = b * b - 4 * a * c;
-  float const sq = sqrtf(disc);
-  float const t = (-b - sq) / (2.0f * a);
+  float const t = near_root(b, disc, 2.0f * a, library_math);
   t_out = t;
   return !(disc < 0.0f) && !(t < tmin || t > tmax);  // the reference's two rejections, NaNs included
 }
@@ -409,10 +480,10 @@ struct Lane
 };
 
 // Frame::ForEachRayImpl, ray_tracing/frame.cpp:61-62: direction of sub-sample (sx, sy) given the column's sdx.
-RT_FN f3 primary_dir(const TraceArgs & A, float sdx, float dyp, uint32_t sy)
+RT_FN f3 primary_dir(const TraceArgs & A, float sdx, float dyp, uint32_t sy, bool library_math)
 {
   float const sdy = dyp - A.cell_y * (float)sy / (float)A.s_row;
-  return normalize3((A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * sdx);
+  return normalize3((A.cam_dir * A.znear + A.cam_up * sdy) + A.cam_right * sdx, library_math);
 }
 
 // First sample (sy) of column `item` that this slice owns; >= s_row when it owns none.  The owner of sample
@@ -561,7 +632,7 @@ struct MaterialView
 
 // Material::Scatter for the three materials, ray_tracing/default_materials.cpp:11-67.  Matte and Metal share
 // one normalisation (of n + ball, or of reflect + ball * roughness).
-RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & out_dir, float & out_e)
+RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & out_dir, float & out_e, bool library_math)
 {
   float const dn = dot3(n, rd);
   f3 const refl = rd - n * dn * 2.0f;  // glm::reflect(I, N) = I - N * dot(N, I) * 2
@@ -569,7 +640,7 @@ RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & 
   {
     bool const matte = m.type == RT_MATTE;
     f3 const v = matte ? n + ball : refl + ball * m.roughness;
-    f3 const r = normalize3(v);
+    f3 const r = normalize3(v, library_math);
     out_dir = r;
     out_e = matte ? 0.7f : ((dot3(n, r) <= 0.0f) ? 0.0f : m.e_metal);
   }
@@ -607,11 +678,11 @@ RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & 
 // DirectionalLight::GetSpecular, ray_tracing/directional_light.cpp:37-60.  The half vector and the cosines are
 // computed exactly (the Beckmann exponent multiplies their rounding by up to 1 / 0.03^2); the three quotients
 // and the exponential behind them only scale the result and use the hardware reciprocal and exp2 (~1e-6).
-RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, const MaterialView & m, f3 rd, f3 n)
+RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, const MaterialView & m, f3 rd, f3 n, bool library_math)
 {
   float const vdn = clampf(dot3(-rd, n), 0.0f, 1.0f);
   float const ndl = clampf(dot3(n, -ldir), 0.0f, 1.0f);
-  f3 const h = -normalize3(ldir + rd);
+  f3 const h = -normalize3(ldir + rd, library_math);
   float const ndh = clampf(dot3(n, h), RT_EPS, 1.0f);
   float const vdh = clampf(dot3(-rd, h), 0.0f, 1.0f);
   float const g = (fabsf(vdh) >= RT_EPS) ? minf(1.0f, 2.0f * ndh * minf(vdn, ndl) * hw_rcp(vdh)) : 1.0f;
@@ -832,6 +903,8 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 }
 
 // What the enclosing kernel provides (Env):
+//   kLibraryMath      exact square roots and quotients come from the compiler's general IEEE sequences, not from
+//                     sqrt_rn_core / div_rn_core: for scenes outside the bounds under which those are exact
 //   kFilterUnroll     spheres per trip of the six-ray filter's main loop (4 costs a dozen registers more than
 //                     2, the difference between three and four waves per SIMD)
 //   any(p)            true if p holds for any lane sharing this lane's loop trips (the wave; the block when
@@ -925,7 +998,7 @@ RT_FN void grid_trace(const TraceArgs & A, Env & env, bool active, f3 o, f3 d, f
     int const i = (int)A.grid_big[k];
     float t;
     cnt.exact_tests += 1;
-    if (exact_hit(o, d, a, env.sphere(i), tmin, tmax, t) && (best_i < 0 || t < best_t || (t == best_t && i < best_i)))
+    if (exact_hit(o, d, a, env.sphere(i), tmin, tmax, t, Env::kLibraryMath) && (best_i < 0 || t < best_t || (t == best_t && i < best_i)))
     {
       best_i = i;
       best_t = t;
@@ -955,7 +1028,7 @@ RT_FN void grid_trace(const TraceArgs & A, Env & env, bool active, f3 o, f3 d, f
       int const i = (int)A.grid_items[k];
       float t;
       cnt.exact_tests += 1;
-      if (exact_hit(o, d, a, env.sphere(i), tmin, tmax, t) && (best_i < 0 || t < best_t || (t == best_t && i < best_i)))
+      if (exact_hit(o, d, a, env.sphere(i), tmin, tmax, t, Env::kLibraryMath) && (best_i < 0 || t < best_t || (t == best_t && i < best_i)))
       {
         best_i = i;
         best_t = t;
@@ -994,7 +1067,7 @@ RT_FN void resolve_primary(const TraceArgs & A, Env & env, uint32_t mask, uint32
       int const i = (int)(base + pop_candidate(mask, count));
       float t;
       cnt.exact_tests += 1;
-      if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t) && (best_i < 0 || t < best_t))
+      if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t, Env::kLibraryMath) && (best_i < 0 || t < best_t))
       {
         best_i = i;
         best_t = t;
@@ -1027,7 +1100,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
         int const i = (int)pop_group(mask);
         float t;
         cnt.exact_tests += 1;
-        if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t) && (best_i < 0 || t < best_t))
+        if (exact_hit(A.cam_pos, dir, a, env.sphere(i), A.znear, A.zfar, t, Env::kLibraryMath) && (best_i < 0 || t < best_t))
         {
           best_i = i;
           best_t = t;
@@ -1080,6 +1153,7 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
     return occluded;
   }
   uint32_t live = rays_on;  // rays still looking for a hit
+  bool const library_math = Env::kLibraryMath;
   near_i = -1;
   near_t = 0.0f;
   constexpr uint32_t kShadowRays = (1u << RT_LIGHT_SAMPLES) - 1u;
@@ -1158,9 +1232,9 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
           unsigned long long m0 = h0 ? mask[r] : 0x8000000000000000ull, m1 = h1 ? mask[r + 1] : 0x8000000000000000ull;
           int const i0 = (int)(base + pop_group(m0)), i1 = (int)(base + pop_group(m1));
           float t0, t1;
-          bool const hit0 = exact_hit_flat(o, dir[r], a[r], env.sphere(i0), 0.001f, 1000.0f, t0) && h0;
+          bool const hit0 = exact_hit_flat(o, dir[r], a[r], env.sphere(i0), 0.001f, 1000.0f, t0, library_math) && h0;
           bool const last = (r + 1 == RT_RAYS - 1);
-          bool const hit1 = exact_hit_flat(o, dir[r + 1], a[r + 1], env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1) && h1;
+          bool const hit1 = exact_hit_flat(o, dir[r + 1], a[r + 1], env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1, library_math) && h1;
           cnt.exact_tests += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
           live = hit0 ? (live & ~(1u << r)) : live;
           mask[r] = (hit0 || !h0) ? 0ull : m0;
@@ -1217,6 +1291,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
   L.sum = L.hp = L.hn = L.hd = L.spec = L.diffuse = L.m_albedo = L.sdir = mk3(0.0f, 0.0f, 0.0f);
   L.sdx = L.dyp = 0.0f;
   bool const deterministic = (A.flags & RT_FLAG_DETERMINISTIC) != 0u;
+  bool const library_math = Env::kLibraryMath;
 
   for (;;)
   {
@@ -1282,7 +1357,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         f3 d = mk3(0.0f, 0.0f, 1.0f);
         if (active)
         {
-          d = primary_dir(A, L.sdx, L.dyp, L.sy);
+          d = primary_dir(A, L.sdx, L.dyp, L.sy, library_math);
           L.sy += A.slice_count;
         }
         float const a = dot3(d, d);
@@ -1303,7 +1378,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             cnt.hits += 1;
             f4 const sp = env.sphere(hi);
             L.hp = A.cam_pos + d * t;  // Ray::PointAt
-            L.hn = normalize3(L.hp - mk3(sp.x, sp.y, sp.z));
+            L.hn = normalize3(L.hp - mk3(sp.x, sp.y, sp.z), library_math);
             L.hd = d;
             L.hidx = hi;
             L.has_hit = true;
@@ -1364,7 +1439,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         ball = ball3(1.0f, uniform24(rw.x), uniform24(rw.y), uniform24(rw.z));
         xi = uniform24(rw.w);
       }
-      scatter(mv, L.hd, L.hn, ball, xi, L.sdir, L.e);
+      scatter(mv, L.hd, L.hn, ball, xi, L.sdir, L.e, library_math);
       L.has_hit = false;
       if (fabsf(L.e) < RT_EPS)
       {
@@ -1380,7 +1455,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         {
           f4 const l0 = env.light(li, 0u);
           f4 const l1 = env.light(li, 1u);
-          L.spec = L.spec + specular(mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), L.m_albedo, mv, L.hd, L.hn);
+          L.spec = L.spec + specular(mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), L.m_albedo, mv, L.hd, L.hn, library_math);
         }
         L.diffuse = mk3(0.0f, 0.0f, 0.0f);
         L.li = 0;
@@ -1427,7 +1502,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       {
         // No jitter: the five shadow rays are one ray, normalised exactly as the reference does
         // (ray_tracing/directional_light.cpp:20), so that a shadow edge never falls between two roundings.
-        f3 const rd = normalize3(to_light);
+        f3 const rd = normalize3(to_light, library_math);
         float const aa = dot3(rd, rd);
         float const ww = maxf(0.0f, dot3(rd, L.hn));
 #pragma unroll
@@ -1532,7 +1607,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
             cnt.hits += 1;
             f4 const sp = env.sphere(L.nx_i);
             f3 const p = L.hp + L.sdir * L.nx_t;
-            L.hn = normalize3(p - mk3(sp.x, sp.y, sp.z));
+            L.hn = normalize3(p - mk3(sp.x, sp.y, sp.z), library_math);
             L.hp = p;
             L.hd = L.sdir;
             L.hidx = L.nx_i;

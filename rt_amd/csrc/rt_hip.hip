@@ -254,8 +254,10 @@ __device__ __forceinline__ void append_split(const TraceArgs & A, uint32_t slot,
 }
 
 // The whole scene is resident in LDS; waves never wait for each other.
+template <bool kLibMath>
 struct WaveEnv
 {
+  static constexpr bool kLibraryMath = kLibMath;
   static constexpr uint32_t kFilterUnroll = RT_WAVE_UNROLL;
   const TraceArgs & A;
   const f4 * filt;       // LDS: n_padded filter records
@@ -347,8 +349,10 @@ struct WaveEnv
 
 // Larger scenes: the block re-stages the spheres (or the camera table) through one LDS tile inside every
 // pass, so all of its waves take the same trips and every loop decision is block-wide.
+template <bool kLibMath>
 struct BlockEnv
 {
+  static constexpr bool kLibraryMath = kLibMath;
   static constexpr uint32_t kFilterUnroll = RT_BLOCK_UNROLL;  // almost all of this path's time is the filter
   const TraceArgs & A;
   f4 * tile;              // LDS: kTileSpheres entries
@@ -396,8 +400,10 @@ struct BlockEnv
 
 // Grid walks: every ray finds its own spheres, read from global memory (the L2 holds the scene); waves never
 // wait for each other.  The tile functions are unused.
+template <bool kLibMath>
 struct GridEnv
 {
+  static constexpr bool kLibraryMath = kLibMath;
   static constexpr uint32_t kFilterUnroll = 2;
   const TraceArgs & A;
   const float * jitter;  // LDS: RT_JITTER_FLOATS
@@ -474,7 +480,8 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
 
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
-template <bool kTiled, bool kForward, bool kOneLight>
+// kLibMath: see rt_core.h Env::kLibraryMath (only the kernels for any number of lights come in that form).
+template <bool kTiled, bool kForward, bool kOneLight, bool kLibMath = false>
 __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : (kTiled && kForward ? RT_TILED_WAVES : kWavesPerSimd)) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   if constexpr (kTiled)
   {
     __syncthreads();
-    BlockEnv env{A, sph, reinterpret_cast<float *>(sph + kTileSpheres), kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool()};
+    BlockEnv<kLibMath> env{A, sph, reinterpret_cast<float *>(sph + kTileSpheres), kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
-    WaveEnv env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
+    WaveEnv<kLibMath> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 
 // The same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).  LDS: [path stacks, unless
 // kForward][jitter table].
-template <bool kForward, bool kOneLight>
+template <bool kForward, bool kOneLight, bool kLibMath = false>
 __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel_grid(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
 #if defined(RT_PROFILE_REGIONS)
   cnt.last_tick = __builtin_amdgcn_s_memtime();
 #endif
-  GridEnv env{A, jitter, ItemPool()};
+  GridEnv<kLibMath> env{A, jitter, ItemPool()};
   trace_loop<kForward, true, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   flush_counters(A, cnt);
 }
@@ -796,6 +803,8 @@ struct rt_hip_scene
   uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
   bool forward_ok = false;  // paths can be accumulated forward (rt_prep.h forward_accumulation_ok)
   ShadowCone cone0;         // shadow cone of light 0 (kernels specialised for one light take it as an argument)
+  bool in_bounds = false;   // the sizes rt_core.h near_root and inv_sqrt_rn ask for: centres within 2^40 of the origin,
+                            // radii and light vectors between 2^-40 and 2^40 long, roughness at most 2^40
   // Blocks per compute unit of the trace kernel this scene is traced with, asked of the runtime once per kernel
   // variant ([1]: the grid walk) and LDS size rather than on every launch.
   struct Occupancy
@@ -804,7 +813,7 @@ struct rt_hip_scene
     bool tiled = false;
     int per_cu = 0;
   };
-  mutable Occupancy occupancy[2];
+  mutable Occupancy occupancy[4];
   // uniform grid for RT_HIP_FLAG_GRID traces (scenes of at least kGridMinSpheres spheres)
   bool has_grid = false;
   uint32_t * d_grid_start = nullptr;
@@ -900,9 +909,19 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
 // The kernel for a scene: resident / tiled / grid walk, stack or forward accumulation; the forward kernels of
 // the resident and the grid path also come specialised for scenes with exactly one light.
 template <class Launch>
-auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
+auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_math, Launch && go)
 {
   bool const one = sc->n_lights == 1u;
+  if (library_math)
+  {
+    // scenes or cameras outside the bounds of the short exact sequences: the general kernels, built with the
+    // compiler's IEEE square root and division throughout
+    if (uses_grid(sc, flags))
+      return sc->forward_ok ? go(trace_kernel_grid<true, false, true>) : go(trace_kernel_grid<false, false, true>);
+    if (is_tiled(sc))
+      return sc->forward_ok ? go(trace_kernel<true, true, false, true>) : go(trace_kernel<true, false, false, true>);
+    return sc->forward_ok ? go(trace_kernel<false, true, false, true>) : go(trace_kernel<false, false, false, true>);
+  }
   if (uses_grid(sc, flags))
   {
     if (!sc->forward_ok)
@@ -920,6 +939,17 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
   return one ? go(trace_kernel<false, true, true>) : go(trace_kernel<false, true, false>);
 }
 
+// The short exact sequences need the scene and the camera within 2^40 of the origin and a near plane between 2^-20
+// and 2^40 (rt_core.h near_root, inv_sqrt_rn); otherwise, and with RT_HIP_LIBRARY_MATH set (any value, for
+// comparisons), a frame is traced by the kernels built with the compiler's sequences.
+bool needs_library_math(const rt_hip_scene * sc, const rt_hip_camera * camera)
+{
+  bool in_bounds = sc->in_bounds && camera->znear >= 0x1p-20f && camera->znear <= 0x1p40f;
+  for (int k = 0; k < 3; ++k)
+    in_bounds = in_bounds && std::fabs(camera->position[k]) <= 0x1p40f;
+  return !in_bounds || std::getenv("RT_HIP_LIBRARY_MATH") != nullptr;
+}
+
 // Persistent grid: as many blocks as the chip holds at once (more would only queue behind them), but no
 // more lanes than work items -- and fewer for small frames.  A lane traces its samples one after the other, a path
 // of ten bounces is ten trips round the loop, and a trip takes as long as the waves that share the SIMD make it
@@ -929,15 +959,15 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, Launch && go)
 // 0.41 ms, 1920x1080 2x2 1.04 -> 1.00 ms); never below one wave per SIMD.  Tiled scenes keep the full grid: their
 // blocks move in step and the samples cost a hundred times as much.
 constexpr unsigned long long kSamplesPerLane = 36;
-int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, unsigned long long items, unsigned long long samples,
-                      bool leave_room)
+int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, bool library_math, unsigned long long items,
+                      unsigned long long samples, bool leave_room)
 {
   size_t const lds = lds_bytes(sc, flags);
-  rt_hip_scene::Occupancy & cached = sc->occupancy[uses_grid(sc, flags) ? 1 : 0];
+  rt_hip_scene::Occupancy & cached = sc->occupancy[(uses_grid(sc, flags) ? 1 : 0) + (library_math ? 2 : 0)];
   if (cached.lds != lds || cached.tiled != is_tiled(sc) || cached.per_cu < 1)
   {
     int asked = 0;
-    hipError_t const e = with_trace_kernel(sc, flags, [&](auto kernel) {
+    hipError_t const e = with_trace_kernel(sc, flags, library_math, [&](auto kernel) {
       return hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked, kernel, kBlock, lds);
     });
     cached.lds = lds;
@@ -1096,12 +1126,13 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     a.grid_cell = scene->grid_cell;
     a.grid_inv_cell = 1.0f / scene->grid_cell;
   }
+  bool const library_math = needs_library_math(scene, camera);
   a.column_masks = (uses_column_masks(scene) && !uses_grid(scene, p->flags)) ? 1u : 0u;
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
   bool const leave_room = (p->flags & RT_HIP_FLAG_LEAVE_ROOM) != 0u ||
                           (d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples);
-  int const blocks = persistent_blocks(scene, p->flags, a.n_items, (unsigned long long)a.n_items * a.s_row / a.slice_count,
-                                       leave_room);
+  int const blocks = persistent_blocks(scene, p->flags, library_math, a.n_items,
+                                       (unsigned long long)a.n_items * a.s_row / a.slice_count, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   size_t const lds = lds_bytes(scene, p->flags);
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
@@ -1124,7 +1155,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   if (ev_start)
     RT_CHECK(hipEventRecord(ev_start, stream));
-  (void)with_trace_kernel(scene, p->flags, [&](auto kernel) {
+  (void)with_trace_kernel(scene, p->flags, library_math, [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, stream, a);
     return hipSuccess;
   });
@@ -1450,6 +1481,17 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   s->n_materials = material_count;
   s->n_lights = light_count;
   s->cone0 = shadow_cone(light_count ? lights[0].direction : nullptr, light_count != 0u && !cones_disabled());
+  s->in_bounds = true;
+  for (size_t k = 0; k < 4u * (size_t)sphere_count; ++k)
+    s->in_bounds = s->in_bounds && std::fabs(centers_radii[k]) <= 0x1p40f && (k % 4u != 3u || std::fabs(centers_radii[k]) >= 0x1p-40f);
+  for (uint32_t k = 0; k < material_count; ++k)
+    s->in_bounds = s->in_bounds && std::fabs(materials[k].roughness) <= 0x1p40f;
+  for (uint32_t k = 0; k < light_count; ++k)
+  {
+    double const len = std::sqrt((double)lights[k].direction[0] * lights[k].direction[0] + (double)lights[k].direction[1] * lights[k].direction[1] +
+                                 (double)lights[k].direction[2] * lights[k].direction[2]);
+    s->in_bounds = s->in_bounds && len >= 0x1p-40 && len <= 0x1p40;
+  }
   s->forward_ok = forward_accumulation_ok(materials, material_count) && std::getenv("RT_HIP_FORCE_STACK") == nullptr;
   auto upload = [](void ** dst, const void * src, size_t bytes) -> hipError_t {
     // Never a zero-byte allocation: keep the pointer valid for empty arrays.
@@ -1843,6 +1885,109 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
 }
 
 }  // extern "C"
+
+// ---- self-check of rt_core.h's short correctly rounded sequences against the compiler's, on this device ----
+namespace
+{
+__device__ __forceinline__ bool same_float(float a, float b)
+{
+  return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);  // any NaN equals any NaN
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+// A float of random sign and mantissa with its exponent in [-60, 60].
+__device__ __forceinline__ float moderate_float(uint32_t h)
+{
+  uint32_t const exponent = 127u - 60u + (h >> 9) % 121u;
+  return __uint_as_float((h & 0x80000000u) | (exponent << 23) | (mix32(h) & 0x007FFFFFu));
+}
+// out[0]: sqrt_rn_core, out[1]: inv_sqrt_rn, each over every float they are specified for; out[2]:
+// div_rn_core on one pair per float pattern (half of the denominators within 2^-8 of 2, where the exact
+// intersection's denominators lie); out[3]: near_root, short sequences against library_math, on discriminants and
+// operands that include zeros, tiny, infinite and NaN discriminants and rays that start on the sphere.
+__global__ __launch_bounds__(256) void exact_math_check_kernel(unsigned long long * out)
+{
+  unsigned long long bad[4] = {0ull, 0ull, 0ull, 0ull};
+  unsigned long long const stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < (1ull << 32); k += stride)
+  {
+    uint32_t const i = (uint32_t)k;
+    float const x = __uint_as_float(i);
+    bool const tiny = (i & 0x7FFFFFFFu) >= 1u && (i & 0x7FFFFFFFu) < 0x0F800000u;  // of either sign
+    if (!tiny && !same_float(sqrt_rn_core(x), sqrtf(x)))
+      bad[0] += 1ull;
+    bool const in_range = (i >= 0x0F800000u && i < 0x6F800000u) || x != x;
+    if (in_range && !same_float(inv_sqrt_rn(x, false), 1.0f / sqrtf(x)))
+      bad[1] += 1ull;
+    uint32_t const h = mix32(i), g = mix32(i ^ 0x9E3779B9u);
+    float const d = (h & 1u) ? __uint_as_float(0x40000000u + ((h >> 1) & 0xFFFFu) - 0x8000u) : moderate_float(h);
+    float const n = ((g & 63u) == 0u) ? 0.0f : moderate_float(g);
+    float const q = div_rn_core(n, d), q_ref = n / d;
+    if (!(same_float(q, q_ref) || (n == 0.0f && q == 0.0f)))
+      bad[2] += 1ull;
+    // operands as the library's bounds leave them: |b| < 2^44, 0 <= disc < 2^90 or negative, or NaN for both
+    float disc = fabsf(moderate_float(g)) * 0x1p29f;
+    float b = moderate_float(mix32(h ^ g)) * 0x1p-17f;
+    switch (i & 31u)
+    {
+    case 0: disc = 0.0f; break;
+    case 1: disc = __uint_as_float(g & 0x0FFFFFFFu); break;   // denormals and tiny numbers
+    case 2: disc = 0x1.fffffep89f; break;
+    case 3: disc = b = __uint_as_float(0x7FC00000u); break;
+    case 4: disc = -disc; break;
+    case 5: disc = b * b; break;                               // a ray that starts on the sphere: -b - |b|
+    case 6: disc = b * b * 0.99999f; break;
+    default: break;
+    }
+    float const d2 = __uint_as_float(0x40000000u + ((h >> 1) & 0xFFu) - 0x80u);
+    float const t = near_root(b, disc, d2, false), t_ref = near_root(b, disc, d2, true);
+    // the contract: identical wherever the reference's own tests (disc < 0, t < tmin, t > tmax with tmin >= 2^-20)
+    // let the distance through
+    bool const used = !(disc < 0.0f) && !(t_ref < 0x1p-20f || t_ref > 0x1p59f);
+    bool const used_short = !(disc < 0.0f) && !(t < 0x1p-20f || t > 0x1p59f);
+    if (used != used_short || (used && !same_float(t, t_ref)))
+      bad[3] += 1ull;
+  }
+  for (int c = 0; c < 4; ++c)
+  {
+    unsigned long long v = bad[c];
+    for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_down(v, off);
+    if (__lane_id() == 0 && v != 0ull)
+      atomicAdd(&out[c], v);
+  }
+}
+}  // namespace
+
+extern "C" int rt_hip_check_exact_math(uint64_t * mismatches4)
+{
+  if (!g_lib.ready)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_init has not been called");
+  if (mismatches4 == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  unsigned long long * d_out = nullptr;
+  RT_CHECK(hipMalloc((void **)&d_out, 4 * sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), g_lib.stream);
+  if (e == hipSuccess)
+  {
+    hipLaunchKernelGGL(exact_math_check_kernel, dim3(std::max(g_lib.compute_units, 1) * 8), dim3(256), 0, g_lib.stream, d_out);
+    e = hipGetLastError();
+  }
+  unsigned long long host[4] = {0, 0, 0, 0};
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(host, d_out, sizeof(host), hipMemcpyDeviceToHost, g_lib.stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(g_lib.stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERR_DEVICE, "rt_hip_check_exact_math", e);
+  for (int c = 0; c < 4; ++c)
+    mismatches4[c] = host[c];
+  return RT_HIP_OK;
+}
 
 #if defined(RT_PROFILE_REGIONS)
 // Profiling builds only: copies out and clears the per-wave timeline of the last resident-kernel launch

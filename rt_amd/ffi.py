@@ -114,6 +114,7 @@ HIP_SYMBOLS = {
         C.c_int,
         [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(Stats)],
     ),
+    "rt_hip_check_exact_math": (C.c_int, [C.POINTER(C.c_uint64)]),
 }
 
 HOST_SYMBOLS = {
@@ -366,6 +367,12 @@ class HipRenderer:
             "rt_hip_time_trace_kernel",
         )
         return ms.value, stats
+
+    def check_exact_math(self):
+        """Mismatch counts of the device self-check of the short correctly rounded sqrt / quotient sequences."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.rt_hip_check_exact_math(out), "rt_hip_check_exact_math")
+        return [int(v) for v in out]
 
     def close(self):
         for handle, _ in self._scenes.values():

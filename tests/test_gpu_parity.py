@@ -316,3 +316,38 @@ def test_accumulate_pass_through_lds_changes_no_bit(hip, ffi, scenes, monkeypatc
         b, _ = hip.render(scene, p)
         monkeypatch.delenv("RT_HIP_PLAIN_COLSUM")
         np.testing.assert_array_equal(a, b)
+
+
+def test_short_exact_sequences_equal_the_compilers(hip):
+    """Exact intersections and normalisations take correctly rounded square roots and quotients from sequences shorter
+    than the compiler's general ones (rt_core.h sqrt_rn_core, div_rn_core).  The device compares them: sqrt and
+    1 / sqrt over every float, the quotient and the near root on one operand set per float pattern."""
+    assert hip.check_exact_math() == [0, 0, 0, 0]
+
+
+def test_library_math_changes_no_bit(hip, ffi, scenes, monkeypatch):
+    """RT_HIP_LIBRARY_MATH makes every exact intersection use the compiler's IEEE sequences: same frames, same
+    counters, in deterministic and stochastic mode, brute force and grid."""
+    for demo, spheres, flags in ((1, 0, 0), (2, 0, 0), (3, 300, 0), (3, 300, ffi.FLAG_GRID), (1, 0, ffi.FLAG_DETERMINISTIC)):
+        scene = scenes(demo, 1, spheres)
+        p = ffi.params(160, 120, 4, seed=11, flags=flags)
+        a, sa = hip.render(scene, p)
+        monkeypatch.setenv("RT_HIP_LIBRARY_MATH", "1")
+        b, sb = hip.render(scene, p)
+        monkeypatch.delenv("RT_HIP_LIBRARY_MATH")
+        np.testing.assert_array_equal(a, b)
+        assert (sa.ray_queries, sa.hit_queries, sa.exact_tests) == (sb.ray_queries, sb.hit_queries, sb.exact_tests)
+
+
+def test_a_near_plane_below_the_short_sequences_bounds(hip, oracle, ffi):
+    """A camera whose near plane is closer than 2^-20 (or a scene beyond the documented sizes) is traced by the
+    kernels built with the compiler's IEEE sequences: same parity with the CPU path."""
+    scene = ffi.Scene.demo(1, 1)
+    scene.camera.znear = 5e-7
+    for flags, depth in ((ffi.FLAG_DETERMINISTIC, 1), (ffi.FLAG_DETERMINISTIC, 0)):
+        p = ffi.params(96, 72, 2, flags=flags, max_depth=depth)
+        ref, rs = oracle.render(scene, p)
+        out, st = hip.render(scene, p)
+        assert rel_err(ref, out).max() < 1e-4
+        assert (st.samples, st.ray_queries, st.hit_queries, st.shaded_bounces) == (rs.samples, rs.ray_queries, rs.hit_queries,
+                                                                                  rs.shaded_bounces)
