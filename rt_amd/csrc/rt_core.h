@@ -226,6 +226,7 @@ RT_FN float div_rn_core(float n, float d) { return n / d; }
 RT_FN float inv_sqrt_rn(float x, bool) { return 1.0f / sqrtf(x); }
 RT_FN float near_root(float b, float disc, float d, bool) { return (-b - sqrtf(disc)) / d; }
 #endif
+RT_FN float exact_sqrt(float x, bool library_math) { return library_math ? sqrtf(x) : sqrt_rn_core(x); }
 
 // ---- exact helpers: the GLSL definitions glm follows, IEEE sqrt and division ----
 RT_FN float minf(float a, float b) { return (b < a) ? b : a; }  // std::min
@@ -474,7 +475,7 @@ struct Lane
   // shading in flight
   uint32_t li;      // light of the current shade pass
   f3 spec, diffuse, m_albedo, sdir;
-  float e, m_refraction, s_a;
+  float e, m_refraction;
   float nx_t;
   int nx_i;  // nearest hit of the scattered ray (found during the first light's pass)
 };
@@ -666,7 +667,7 @@ RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & 
     float const k = 1.0f - eta * eta * (1.0f - d * d);
     f3 refr = mk3(0.0f, 0.0f, 0.0f);
     if (k >= 0.0f)
-      refr = rd * eta - outward * (eta * d + sqrtf(k));
+      refr = rd * eta - outward * (eta * d + exact_sqrt(k, library_math));  // k: zero or at least 2^-49
     float ref = 1.0f;
     if (dot3(refr, refr) > RT_EPS)
       ref = m.f2 + (1.0f - m.f2) * pow5(1.0f - vdn);
@@ -1134,8 +1135,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
 // rays_on: bit r set if ray r of this lane is to be traced.  Returns the shadow rays found occluded as bits
 // 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.  `cone` holds dir[0..4].
 template <bool kGrid, bool kOneLight, class Env>
-RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const float (&a)[RT_RAYS],
-                          const ShadowCone & cone, uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
+RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const ShadowCone & cone, uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
 {
   if constexpr (kGrid)
   {
@@ -1145,10 +1145,10 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
     {
       float t;
       int i;
-      grid_trace(A, env, ((rays_on >> r) & 1u) != 0u, o, dir[r], a[r], 0.001f, 1000.0f, true, t, i, cnt);
+      grid_trace(A, env, ((rays_on >> r) & 1u) != 0u, o, dir[r], dot3(dir[r], dir[r]), 0.001f, 1000.0f, true, t, i, cnt);
       occluded |= (i >= 0) ? (1u << r) : 0u;
     }
-    grid_trace(A, env, ((rays_on >> (RT_RAYS - 1)) & 1u) != 0u, o, dir[RT_RAYS - 1], a[RT_RAYS - 1], 0.001f, A.zfar,
+    grid_trace(A, env, ((rays_on >> (RT_RAYS - 1)) & 1u) != 0u, o, dir[RT_RAYS - 1], dot3(dir[RT_RAYS - 1], dir[RT_RAYS - 1]), 0.001f, A.zfar,
                false, near_t, near_i, cnt);
     return occluded;
   }
@@ -1232,9 +1232,11 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
           unsigned long long m0 = h0 ? mask[r] : 0x8000000000000000ull, m1 = h1 ? mask[r + 1] : 0x8000000000000000ull;
           int const i0 = (int)(base + pop_group(m0)), i1 = (int)(base + pop_group(m1));
           float t0, t1;
-          bool const hit0 = exact_hit_flat(o, dir[r], a[r], env.sphere(i0), 0.001f, 1000.0f, t0, library_math) && h0;
+          // a = dot(D, D) of Sphere::TraceNearest (ray_tracing/sphere.cpp:66) is taken here, where a candidate
+          // needs it, not carried through the filter for all six rays
+          bool const hit0 = exact_hit_flat(o, dir[r], dot3(dir[r], dir[r]), env.sphere(i0), 0.001f, 1000.0f, t0, library_math) && h0;
           bool const last = (r + 1 == RT_RAYS - 1);
-          bool const hit1 = exact_hit_flat(o, dir[r + 1], a[r + 1], env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1, library_math) && h1;
+          bool const hit1 = exact_hit_flat(o, dir[r + 1], dot3(dir[r + 1], dir[r + 1]), env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1, library_math) && h1;
           cnt.exact_tests += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
           live = hit0 ? (live & ~(1u << r)) : live;
           mask[r] = (hit0 || !h0) ? 0ull : m0;
@@ -1287,7 +1289,6 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
   L.nx_t = 0.0f;
   L.e = 0.0f;
   L.m_refraction = 0.0f;
-  L.s_a = 1.0f;
   L.sum = L.hp = L.hn = L.hd = L.spec = L.diffuse = L.m_albedo = L.sdir = mk3(0.0f, 0.0f, 0.0f);
   L.sdx = L.dyp = 0.0f;
   bool const deterministic = (A.flags & RT_FLAG_DETERMINISTIC) != 0u;
@@ -1401,9 +1402,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
 
     // ================= stage S: shade the hits =================
     f3 dir[RT_RAYS];
-    float a[RT_RAYS];
     uint32_t rays_on = 0;
-    float w[RT_LIGHT_SAMPLES];
     // Philox block of the first light's shadow jitter, drawn with the scatter block (the first light's pass is
     // always in the trip that shades the new hit)
     u4 shadow_words;
@@ -1459,7 +1458,6 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         }
         L.diffuse = mk3(0.0f, 0.0f, 0.0f);
         L.li = 0;
-        L.s_a = dot3(L.sdir, L.sdir);
         L.nx_i = -1;
         L.nx_t = 0.0f;
         L.shading = true;
@@ -1503,15 +1501,9 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         // No jitter: the five shadow rays are one ray, normalised exactly as the reference does
         // (ray_tracing/directional_light.cpp:20), so that a shadow edge never falls between two roundings.
         f3 const rd = normalize3(to_light, library_math);
-        float const aa = dot3(rd, rd);
-        float const ww = maxf(0.0f, dot3(rd, L.hn));
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
-        {
           dir[j] = rd;
-          a[j] = aa;
-          w[j] = ww;
-        }
       }
       else
       {
@@ -1535,13 +1527,10 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
           float const inv = hw_rsq(fdot3(v, v));
           f3 const rd = v * inv;
           dir[j] = rd;
-          a[j] = fdot3(rd, rd);
-          w[j] = hw_max(0.0f, fdot3(rd, L.hn));
         }
       }
       rays_on = lit ? ((1u << RT_LIGHT_SAMPLES) - 1u) : 0u;
       dir[RT_RAYS - 1] = L.sdir;
-      a[RT_RAYS - 1] = L.s_a;
       rays_on |= (in_pass && L.li == 0u) ? (1u << (RT_RAYS - 1)) : 0u;
     }
 
@@ -1558,7 +1547,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     float near_t;
     int near_i;
     RT_REGION(cnt, 9);
-    uint32_t const occluded = trace_pass<kGrid, kOneLight>(A, env, L.hp, dir, a, cone, rays_on, near_t, near_i, cnt);
+    uint32_t const occluded = trace_pass<kGrid, kOneLight>(A, env, L.hp, dir, cone, rays_on, near_t, near_i, cnt);
 
     if (in_pass)
     {
@@ -1576,8 +1565,11 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
         {
           bool const blocked = ((occluded >> j) & 1u) != 0u;
-          w_blocked += blocked ? w[j] : 0.0f;
-          w_open += blocked ? 0.0f : w[j];
+          // max(0, dot(direction, normal)), directional_light.cpp:24,31 (taken after the trace: five registers
+          // fewer across it)
+          float const wj = deterministic ? maxf(0.0f, dot3(dir[j], L.hn)) : hw_max(0.0f, fdot3(dir[j], L.hn));
+          w_blocked += blocked ? wj : 0.0f;
+          w_open += blocked ? 0.0f : wj;
         }
         cnt.hits += (uint32_t)__builtin_popcount(occluded);
         float const fifth = 1.0f / (float)RT_LIGHT_SAMPLES;
@@ -1626,7 +1618,6 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       L.spec = L.diffuse = L.sdir = L.m_albedo = mk3(0.0f, 0.0f, 0.0f);
       L.e = 0.0f;
       L.m_refraction = 0.0f;
-      L.s_a = 1.0f;
       L.nx_t = 0.0f;
       L.nx_i = -1;
       L.li = 0;
