@@ -124,7 +124,7 @@ typedef struct
   uint64_t exact_tests;    /* exact intersections run: the candidates the filter (or the grid walk) let through */
   uint64_t lane_trips;     /* trips round the kernel's main loop, summed over lanes (busy or idle) */
   uint64_t lane_rounds;    /* primary-ray rounds inside those trips, summed over lanes (busy or idle) */
-  uint64_t cone_tests;     /* spheres a shadow cone touched; each was then tested against the five shadow rays */
+  uint64_t cone_tests;     /* spheres a shadow cone touched; each was then intersected with the shadow rays still unblocked */
   float kernel_ms;         /* device time of the trace kernel, HIP events on the launch stream; 0 if not measured */
   uint32_t reserved;
 } rt_hip_stats;

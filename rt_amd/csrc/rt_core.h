@@ -18,8 +18,8 @@
 //            ray-sphere test is then 3 FMAs and one instruction that shifts the sign of the result into a
 //            per-lane candidate mask.  A small margin keeps the filter conservative.  The five shadow rays
 //            of a light all lie in a narrow cone around the direction to the light, so a pass tests that
-//            cone once per sphere (same cost as one ray) and only the spheres the cone may touch are then
-//            tested against the five rays one by one.
+//            cone once per sphere (same cost as one ray) and only the spheres the cone may touch go on to
+//            the exact intersection, for the five rays at once.
 //   resolve  the few candidates are intersected exactly as Sphere::TraceNearest does
 //            (ray_tracing/sphere.cpp:63-81), operation for operation, with IEEE sqrt and division and
 //            without FMA contraction, keeping the nearest one as TraceNearestInHitableCollection does
@@ -368,7 +368,7 @@ struct LaneCounters
 {
   uint32_t samples, queries, hits, shaded, exact_tests;
   uint32_t filter_tests;  // rays, shadow cones or columns run through the filter; each is n_spheres tests
-  uint32_t cone_tests;    // spheres a shadow cone touched: each was tested against the five shadow rays
+  uint32_t cone_tests;    // spheres a shadow cone touched: each was intersected with the shadow rays still looking
   uint32_t trips, rounds;  // loop trips and stage-P rounds this lane sat through, busy or not
 #if defined(RT_PROFILE_REGIONS)
   // Profiling builds only: wave clock ticks spent in each region of the loop (see RT_REGION).
@@ -865,19 +865,6 @@ RT_FN void filter_chunk_2(const f4 * sph, const float * aux, uint32_t count, f3 
   ray_mask = chunk_candidates(ray_mask, count);
 }
 
-// One sphere the cone may touch against the five shadow rays themselves: bit r of the result is set if ray r
-// passes the filter.
-RT_FN uint32_t filter_sphere_shadow(f4 s, f3 o, const f3 (&dir)[RT_RAYS])
-{
-  float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
-  float const nb = -filter_bound(dx, dy, dz, s.w);
-  uint32_t rejected = 0;
-#pragma unroll
-  for (int r = RT_LIGHT_SAMPLES - 1; r >= 0; --r)
-    rejected = push_sign(rejected, hw_fma(dz, dir[r].z, hw_fma(dy, dir[r].y, hw_fma(dx, dir[r].x, nb))));
-  return ~rejected & ((1u << RT_LIGHT_SAMPLES) - 1u);
-}
-
 // Candidates of a group of two chunks as one 64-bit mask with sphere j of the group in bit 63 - j (the chunk masks
 // hold entry j of a chunk in bit count - 1 - j).
 RT_FN unsigned long long group_mask(uint32_t lo, uint32_t count_lo, uint32_t hi, uint32_t count_hi)
@@ -1186,73 +1173,52 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       ray_mask = ((live >> (RT_RAYS - 1)) & 1u) ? ray_mask : 0ull;
       if (!env.any_wave((cone_mask | ray_mask) != 0ull))
         continue;
-      // The spheres the cone may touch, against the five shadow rays themselves: one sphere per lane and
-      // iteration, no branches inside.
-      unsigned long long mask[RT_RAYS];
-#pragma unroll
-      for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
-        mask[r] = 0ull;
-      mask[RT_RAYS - 1] = ray_mask;
+      uint32_t const base = tile_base + c0;
+      // Shadow rays, sphere by sphere: a lane takes the next sphere its cone may touch and runs Sphere::TraceNearest
+      // (ray_tracing/sphere.cpp:63-81) for its five rays at once, without branches.  d = o - centre and
+      // c = dot(d, d) - r^2 do not depend on the ray, and the loop goes round as often as the lane with the most
+      // such spheres needs (seldom more than once) instead of once per pair of rays.  Existence of a hit in
+      // [0.001, 1000] is all TraceLight uses, so a lane whose five rays are all blocked drops its other spheres.
       while (env.any_wave(cone_mask != 0ull))
       {
         RT_COUNT_TRIP(cnt, 12);
         bool const h = cone_mask != 0ull;
-        unsigned long long const m = h ? cone_mask : 1ull;
+        unsigned long long const m = h ? cone_mask : 0x8000000000000000ull;
         uint32_t const j = (uint32_t)hw_clz64(m);
-        unsigned long long const bit = 0x8000000000000000ull >> j;
-        uint32_t const pass = h ? filter_sphere_shadow(sph[c0 + (h ? j : 0u)], o, dir) : 0u;
-        cnt.cone_tests += h ? 1u : 0u;
+        f4 const s = env.sphere((int)(base + j));
+        f3 const d = o - mk3(s.x, s.y, s.z);
+        float const c = dot3(d, d) - s.w;
+        uint32_t const looking = h ? (live & kShadowRays) : 0u;
 #pragma unroll
         for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
-          mask[r] |= ((pass >> r) & 1u) ? bit : 0ull;
-        cone_mask = h ? (m & ~bit) : 0ull;
-      }
-      unsigned long long any_mask = 0ull;
-#pragma unroll
-      for (int r = 0; r < RT_RAYS; ++r)
-      {
-        mask[r] = ((live >> r) & 1u) ? mask[r] : 0ull;
-        any_mask |= mask[r];
-      }
-      if (!env.any_wave(any_mask != 0ull))
-        continue;
-      // Candidates are resolved two rays at a time, without branches inside an iteration: the two exact
-      // intersections are independent chains of dependent instructions (IEEE sqrt and division) and interleave.
-      // Shadow rays: existence of a hit in [0.001, 1000] is all TraceLight uses.  Scattered ray (the last one):
-      // nearest hit, lowest index first so that the first of equal distances wins; secondary hits start at 0.001
-      // (demos/demo_frame_cpu.cpp:53).
-      uint32_t const base = tile_base + c0;
-#pragma unroll
-      for (int r = 0; r < RT_RAYS; r += 2)
-      {
-        while (env.any_wave((mask[r] | mask[r + 1]) != 0ull))
         {
-          RT_COUNT_TRIP(cnt, 13);
-          bool const h0 = mask[r] != 0ull, h1 = mask[r + 1] != 0ull;
-          unsigned long long m0 = h0 ? mask[r] : 0x8000000000000000ull, m1 = h1 ? mask[r + 1] : 0x8000000000000000ull;
-          int const i0 = (int)(base + pop_group(m0)), i1 = (int)(base + pop_group(m1));
-          float t0, t1;
-          // a = dot(D, D) of Sphere::TraceNearest (ray_tracing/sphere.cpp:66) is taken here, where a candidate
-          // needs it, not carried through the filter for all six rays
-          bool const hit0 = exact_hit_flat(o, dir[r], dot3(dir[r], dir[r]), env.sphere(i0), 0.001f, 1000.0f, t0, library_math) && h0;
-          bool const last = (r + 1 == RT_RAYS - 1);
-          bool const hit1 = exact_hit_flat(o, dir[r + 1], dot3(dir[r + 1], dir[r + 1]), env.sphere(i1), 0.001f, last ? A.zfar : 1000.0f, t1, library_math) && h1;
-          cnt.exact_tests += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
-          live = hit0 ? (live & ~(1u << r)) : live;
-          mask[r] = (hit0 || !h0) ? 0ull : m0;
-          if (last)
-          {
-            bool const nearer = hit1 && (near_i < 0 || t1 < near_t);
-            near_i = nearer ? i1 : near_i;
-            near_t = nearer ? t1 : near_t;
-            mask[r + 1] = h1 ? m1 : 0ull;
-          }
-          else
-          {
-            live = hit1 ? (live & ~(1u << (r + 1))) : live;
-            mask[r + 1] = (hit1 || !h1) ? 0ull : m1;
-          }
+          float const a = dot3(dir[r], dir[r]);
+          float const b = 2.0f * dot3(d, dir[r]);
+          float const disc = b * b - 4 * a * c;
+          float const t = near_root(b, disc, 2.0f * a, library_math);
+          bool const hit = !(disc < 0.0f) && !(t < 0.001f || t > 1000.0f) && ((looking >> r) & 1u) != 0u;
+          live = hit ? (live & ~(1u << r)) : live;
         }
+        cnt.cone_tests += h ? 1u : 0u;
+        cnt.exact_tests += (uint32_t)__builtin_popcount(looking);
+        cone_mask = (h && (live & kShadowRays) != 0u) ? (m & ~(0x8000000000000000ull >> j)) : 0ull;
+      }
+      // The scattered ray: nearest hit, lowest index first so that the first of equal distances wins; secondary
+      // hits start at 0.001 (demos/demo_frame_cpu.cpp:53).
+      while (env.any_wave(ray_mask != 0ull))
+      {
+        RT_COUNT_TRIP(cnt, 13);
+        bool const h1 = ray_mask != 0ull;
+        unsigned long long m1 = h1 ? ray_mask : 0x8000000000000000ull;
+        int const i1 = (int)(base + pop_group(m1));
+        float t1;
+        bool const hit1 = exact_hit_flat(o, dir[RT_RAYS - 1], dot3(dir[RT_RAYS - 1], dir[RT_RAYS - 1]), env.sphere(i1),
+                                         0.001f, A.zfar, t1, library_math) && h1;
+        cnt.exact_tests += h1 ? 1u : 0u;
+        bool const nearer = hit1 && (near_i < 0 || t1 < near_t);
+        near_i = nearer ? i1 : near_i;
+        near_t = nearer ? t1 : near_t;
+        ray_mask = h1 ? m1 : 0ull;
       }
       RT_REGION(cnt, 8);
     }

@@ -861,8 +861,8 @@ uint32_t forced_tile()
   return std::min(std::max(n, 1u), kTileSpheres);
 }
 
-// RT_HIP_NO_CONES (any value): scenes created while it is set filter their shadow rays one by one against every
-// sphere instead of testing the cone that holds them first; for comparisons (same frames, same query counters).
+// RT_HIP_NO_CONES (any value): scenes created while it is set intersect their shadow rays with every sphere instead
+// of testing the cone that holds them first; for comparisons (same frames, same query counters).
 bool cones_disabled() { return std::getenv("RT_HIP_NO_CONES") != nullptr; }
 
 // RT_HIP_NO_SHARING (any value) switches sample sharing at the end of the queue off, for comparisons.

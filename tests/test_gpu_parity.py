@@ -210,8 +210,8 @@ def test_full_size_frame_properties(hip, ffi, scenes):
 @pytest.mark.parametrize("demo,spheres,size", [(1, 0, (640, 360, 4)), (2, 0, (320, 180, 6)), (3, 600, (160, 90, 2))],
                          ids=["pretty", "glass", "field600"])
 def test_shadow_cones_change_no_bit(hip, ffi, demo, spheres, size, monkeypatch):
-    """The five shadow rays of a light are filtered as one cone first; scenes created under RT_HIP_NO_CONES filter
-    them one by one against every sphere.  Same frame, same query counters, far fewer filter tests."""
+    """The five shadow rays of a light are filtered as one cone first; scenes created under RT_HIP_NO_CONES intersect
+    them with every sphere.  Same frame, same query counters, far fewer exact intersections."""
     w, h, s = size
     with_cones = ffi.Scene.demo(demo, 1, spheres)
     monkeypatch.setenv("RT_HIP_NO_CONES", "1")
@@ -223,9 +223,9 @@ def test_shadow_cones_change_no_bit(hip, ffi, demo, spheres, size, monkeypatch):
         a, sa = hip.render(with_cones, p)
         b, sb = hip.render(without, p)
         np.testing.assert_array_equal(a, b)
-        assert (sa.samples, sa.ray_queries, sa.hit_queries, sa.shaded_bounces, sa.exact_tests) == \
-               (sb.samples, sb.ray_queries, sb.hit_queries, sb.shaded_bounces, sb.exact_tests)
-        assert sa.sphere_tests == sb.sphere_tests and sa.cone_tests < 0.2 * sb.cone_tests
+        assert (sa.samples, sa.ray_queries, sa.hit_queries, sa.shaded_bounces) == \
+               (sb.samples, sb.ray_queries, sb.hit_queries, sb.shaded_bounces)
+        assert sa.sphere_tests == sb.sphere_tests and sa.cone_tests < 0.2 * sb.cone_tests and sa.exact_tests < sb.exact_tests
 
 
 @pytest.mark.parametrize("spheres", [300, 3000])
@@ -336,7 +336,7 @@ def test_library_math_changes_no_bit(hip, ffi, scenes, monkeypatch):
         b, sb = hip.render(scene, p)
         monkeypatch.delenv("RT_HIP_LIBRARY_MATH")
         np.testing.assert_array_equal(a, b)
-        assert (sa.ray_queries, sa.hit_queries, sa.exact_tests) == (sb.ray_queries, sb.hit_queries, sb.exact_tests)
+        assert (sa.ray_queries, sa.hit_queries, sa.shaded_bounces) == (sb.ray_queries, sb.hit_queries, sb.shaded_bounces)
 
 
 def test_a_near_plane_below_the_short_sequences_bounds(hip, oracle, ffi):

@@ -96,7 +96,7 @@ while time.time() < t_end:
                                        slice_count=g))
     d, sd = r.render(plain[si], sto)  # the same scene without shadow cones
     stable = np.array_equal(a, b) and np.array_equal(a, c) and sa.ray_queries == sb.ray_queries == sc.ray_queries
-    stable = stable and np.array_equal(a, d) and (sa.hit_queries, sa.exact_tests) == (sd.hit_queries, sd.exact_tests)
+    stable = stable and np.array_equal(a, d) and sa.hit_queries == sd.hit_queries
     cases += 1
     if cases % 50 == 0:
         print("%d cases so far, worst deterministic error %.3g" % (cases, worst), flush=True)
