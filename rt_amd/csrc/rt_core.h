@@ -387,7 +387,8 @@ struct LaneCounters
     (cnt).region[k] += now_ - (cnt).last_tick;                              \
     (cnt).last_tick = now_;                                                 \
   } while (0)
-// Slots 12 and 13 count loop trips of a wave, not time: cone spheres against the five rays, and pairs of exact tests.
+// Slots 11 to 13 count loop trips of a wave, not time: a column's candidates against a primary ray, the spheres shadow
+// cones touched, the candidates of scattered rays.
 #define RT_COUNT_TRIP(cnt, k) ((cnt).region[k] += 1ull)
 #elif defined(RT_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
 // Listing aid: leaves "; MARK k" comments in the assembly so that instructions can be counted per region.
@@ -1083,6 +1084,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
     unsigned long long mask = active ? (((unsigned long long)cm0 << 32) | (unsigned long long)cm1) : 0ull;
     while (env.any_wave(mask != 0ull))
     {
+      RT_COUNT_TRIP(cnt, 11);
       if (mask != 0ull)
       {
         int const i = (int)pop_group(mask);
@@ -1527,13 +1529,27 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         // sum of (blocked ? tint : colour) * w_j, gathered as two weights (a colour, not geometry: the last
         // bits may differ from adding sample by sample)
         float w_blocked = 0.0f, w_open = 0.0f;
+        // max(0, dot(direction, normal)), directional_light.cpp:24,31 (taken after the trace: five registers fewer
+        // across it)
+        float w[RT_LIGHT_SAMPLES];
+        if (deterministic)
+        {
+          float const ww = maxf(0.0f, dot3(dir[0], L.hn));  // the five rays are one ray
+#pragma unroll
+          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+            w[j] = ww;
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
+            w[j] = hw_max(0.0f, fdot3(dir[j], L.hn));
+        }
 #pragma unroll
         for (int j = 0; j < RT_LIGHT_SAMPLES; ++j)
         {
           bool const blocked = ((occluded >> j) & 1u) != 0u;
-          // max(0, dot(direction, normal)), directional_light.cpp:24,31 (taken after the trace: five registers
-          // fewer across it)
-          float const wj = deterministic ? maxf(0.0f, dot3(dir[j], L.hn)) : hw_max(0.0f, fdot3(dir[j], L.hn));
+          float const wj = w[j];
           w_blocked += blocked ? wj : 0.0f;
           w_open += blocked ? 0.0f : wj;
         }

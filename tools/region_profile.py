@@ -29,13 +29,14 @@ r.render(sc, p)  # warm-up
 lib.rt_hip_debug_region_ticks(buf, 14)  # reading clears the counters
 out, st = r.render(sc, p)
 lib.rt_hip_debug_region_ticks(buf, 14)
-total = float(sum(buf[:12]))
+total = float(sum(buf[:11]))
 print(st.as_dict())
-for k in range(12):
+for k in range(11):
     print("%6.2f %%  %s" % (100.0 * buf[k] / total, NAMES[k]))
-# slots 12 and 13 count wave-level loop trips (one count per wave and trip) of the two resolution loops
+# slots 11 to 13 count wave-level loop trips (one count per wave and trip) of the three resolution loops
 wave_trips = st.lane_trips / 64.0
-print("per loop trip of a wave: %.2f trips of the cone-sphere loop, %.2f trips of the exact-test pair loops; "
-      "%.2f exact tests and %.2f cone spheres per lane" % (buf[12] / wave_trips, buf[13] / wave_trips,
-                                                           st.exact_tests / st.lane_trips, st.cone_tests / st.lane_trips))
+print("per loop trip of a wave: %.2f primary rounds with %.2f trips of the primary candidate loop, %.2f trips of the "
+      "cone-sphere loop, %.2f trips of the scattered-ray loop; %.2f exact tests and %.2f cone spheres per lane"
+      % (st.lane_rounds / st.lane_trips, buf[11] / wave_trips, buf[12] / wave_trips, buf[13] / wave_trips,
+         st.exact_tests / st.lane_trips, st.cone_tests / st.lane_trips))
 r.close()
