@@ -58,7 +58,10 @@ constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
 constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
 constexpr uint32_t RT_LIGHT_RECORDS = 3; // float4 records per light
-constexpr uint32_t RT_UNROLL = 2;      // camera-table entries per trip of the primary filter's main part
+#ifndef RT_PRIMARY_UNROLL
+#define RT_PRIMARY_UNROLL 4
+#endif
+constexpr uint32_t RT_UNROLL = RT_PRIMARY_UNROLL;      // camera-table entries per trip of the primary filter's main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
 
