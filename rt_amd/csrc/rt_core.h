@@ -58,10 +58,7 @@ constexpr uint32_t RT_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t RT_CHUNK = 32;      // spheres per candidate mask
 constexpr uint32_t RT_MAT_RECORDS = 3; // float4 records per material
 constexpr uint32_t RT_LIGHT_RECORDS = 3; // float4 records per light
-#ifndef RT_PRIMARY_UNROLL
-#define RT_PRIMARY_UNROLL 4
-#endif
-constexpr uint32_t RT_UNROLL = RT_PRIMARY_UNROLL;      // camera-table entries per trip of the primary filter's main part
+constexpr uint32_t RT_UNROLL = 2;      // camera-table entries per trip of the column filter's main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
 
@@ -592,6 +589,7 @@ struct ColumnEntry
 };
 
 // Filter of one ray against `count` (<= RT_CHUNK) camera-table entries; defined below.
+template <uint32_t kUnroll>
 RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir);
 
 // Ray set-up of one column (the arithmetic of begin_item) and its candidate masks: the camera table, whose
@@ -615,9 +613,9 @@ RT_FN ColumnEntry prepare_column(const TraceArgs & A, const f4 * camtab, uint32_
   f3 const dc = normalize3_fast(v);
   // the candidates as a group mask (sphere j in bit 63 - j): cm0 the upper word, spheres 0..31, cm1 the lower
   uint32_t const c0 = (A.n_padded < RT_CHUNK) ? A.n_padded : RT_CHUNK;
-  e.cm0 = (c0 != 0u) ? (filter_chunk_1(camtab, c0, dc) << (32u - c0)) : 0u;
+  e.cm0 = (c0 != 0u) ? (filter_chunk_1<RT_UNROLL>(camtab, c0, dc) << (32u - c0)) : 0u;
   e.cm1 = (A.n_padded > RT_CHUNK)
-              ? (filter_chunk_1(camtab + RT_CHUNK, A.n_padded - RT_CHUNK, dc) << (32u - (A.n_padded - RT_CHUNK)))
+              ? (filter_chunk_1<RT_UNROLL>(camtab + RT_CHUNK, A.n_padded - RT_CHUNK, dc) << (32u - (A.n_padded - RT_CHUNK)))
               : 0u;
   e.sy0 = first_sample(A, item);
   e.pad = 0u;
@@ -779,14 +777,15 @@ RT_FN uint32_t chunk_candidates(uint32_t rejected, uint32_t count)
 
 // Filter of one ray against `count` (<= RT_CHUNK) camera-table entries
 // (centre - camera, bound).
+template <uint32_t kUnroll>
 RT_FN uint32_t filter_chunk_1(const f4 * tab, uint32_t count, f3 dir)
 {
   uint32_t mask = 0;
   uint32_t j = 0;
-  for (; j + RT_UNROLL <= count; j += RT_UNROLL)
+  for (; j + kUnroll <= count; j += kUnroll)
   {
 #pragma unroll
-    for (uint32_t u = 0; u < RT_UNROLL; ++u)
+    for (uint32_t u = 0; u < kUnroll; ++u)
     {
       f4 const e = tab[j + u];
       mask = push_sign(mask, hw_fma(e.z, dir.z, hw_fma(e.y, dir.y, hw_fma(e.x, dir.x, -e.w))));
@@ -897,6 +896,7 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 // What the enclosing kernel provides (Env):
 //   kLibraryMath      exact square roots and quotients come from the compiler's general IEEE sequences, not from
 //                     sqrt_rn_core / div_rn_core: for scenes outside the bounds under which those are exact
+//   kPrimaryUnroll    camera-table entries per trip of the per-sample primary filter's main loop
 //   kFilterUnroll     spheres per trip of the six-ray filter's main loop (4 costs a dozen registers more than
 //                     2, the difference between three and four waves per SIMD)
 //   any(p)            true if p holds for any lane sharing this lane's loop trips (the wave; the block when
@@ -1112,7 +1112,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
     {
       uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
       RT_REGION(cnt, 1);
-      uint32_t mask = filter_chunk_1(tab + c0, count, dir);
+      uint32_t mask = filter_chunk_1<Env::kPrimaryUnroll>(tab + c0, count, dir);
       if (!active)
         mask = 0;
       RT_REGION(cnt, 2);
@@ -1197,8 +1197,15 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
 #pragma unroll
         for (int r = 0; r < RT_LIGHT_SAMPLES; ++r)
         {
-          float const a = dot3(dir[r], dir[r]);
-          float const b = 2.0f * dot3(d, dir[r]);
+          float dx = dir[r].x;
+#if defined(__HIP_DEVICE_COMPILE__)
+          // keeps dot(D, D), 2a and 4a of the five rays from being computed ahead of the loop and held in a dozen
+          // registers across it (and across every group of a tiled scene) for five multiplications per sphere
+          asm volatile("" : "+v"(dx));
+#endif
+          f3 const dr = mk3(dx, dir[r].y, dir[r].z);
+          float const a = dot3(dr, dr);
+          float const b = 2.0f * dot3(d, dr);
           float const disc = b * b - 4 * a * c;
           float const t = near_root(b, disc, 2.0f * a, library_math);
           bool const hit = !(disc < 0.0f) && !(t < 0.001f || t > 1000.0f) && ((looking >> r) & 1u) != 0u;

@@ -259,6 +259,7 @@ struct WaveEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
   static constexpr uint32_t kFilterUnroll = RT_WAVE_UNROLL;
+  static constexpr uint32_t kPrimaryUnroll = 2;  // scenes of 65 to 256 spheres; smaller ones filter per column
   const TraceArgs & A;
   const f4 * filt;       // LDS: n_padded filter records
   const f4 * cam;        // LDS: n_padded camera-table records
@@ -354,6 +355,10 @@ struct BlockEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
   static constexpr uint32_t kFilterUnroll = RT_BLOCK_UNROLL;  // almost all of this path's time is the filter
+#ifndef RT_BLOCK_PRIMARY_UNROLL
+#define RT_BLOCK_PRIMARY_UNROLL 4
+#endif
+  static constexpr uint32_t kPrimaryUnroll = RT_BLOCK_PRIMARY_UNROLL;
   const TraceArgs & A;
   f4 * tile;              // LDS: kTileSpheres entries
   float * tile_cone;      // LDS: kTileSpheres cone terms, staged with the filter records
@@ -405,6 +410,7 @@ struct GridEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
   static constexpr uint32_t kFilterUnroll = 2;
+  static constexpr uint32_t kPrimaryUnroll = 2;
   const TraceArgs & A;
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ItemPool pool;

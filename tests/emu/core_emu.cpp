@@ -11,6 +11,7 @@ namespace
 struct HostEnv
 {
   static constexpr uint32_t kFilterUnroll = 4;
+  static constexpr uint32_t kPrimaryUnroll = 4;
   static constexpr bool kLibraryMath = true;  // (the host build has no other)
   const rtc::TraceArgs & A;
   uint32_t total;
