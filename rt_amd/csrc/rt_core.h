@@ -61,6 +61,10 @@ constexpr uint32_t RT_LIGHT_RECORDS = 3; // float4 records per light
 constexpr uint32_t RT_UNROLL = 2;      // camera-table entries per trip of the column filter's main part
 constexpr int RT_P_THRESHOLD = 8;      // stage P repeats while more lanes than this still need a hit
 constexpr double RT_FILTER_MARGIN = 2e-6;  // relative slack of the filter's c = |O-C|^2 - r^2
+// The shade filter takes |O-C|^2 and dot(C-O, D) apart into products of the two points (see filter_sphere_2), whose
+// rounding errors grow with the points' distances from the scene's centre, not with |O-C|: it is made up for by
+// RT_FILTER_SLACK times the sum of the two squared distances (the errors add up to less than 2.2e-6 times it).
+constexpr double RT_FILTER_SLACK = 4e-6;
 
 constexpr uint32_t RT_MATTE = 0, RT_METAL = 1, RT_GLASS = 2;  // ray_tracing/types.hpp:15-17
 constexpr uint32_t RT_FLAG_DETERMINISTIC = 1u;
@@ -299,10 +303,12 @@ struct TraceArgs
 {
   // scene, device memory
   const f4 * spheres;          // n_padded x (cx, cy, cz, r*r): what the exact intersection reads
-  const f4 * filter;           // n_padded x (cx, cy, cz, square of the radius widened by the filter margin)
-  const float * aux_rw;        // n_padded x the widened radius itself: what a shadow-cone test adds per sphere ...
+  const f4 * filter;           // n_padded x (centre - scene centre, the sphere's constant of the shade filter): see
+                               // filter_sphere_2 and rt_prep.h flatten_scene
+  const float * aux_rw;        // n_padded x the widened radius: what a shadow-cone test adds per sphere ...
   const float * aux_cone;      // ... and, for kernels specialised for one light, the whole sphere-dependent part of
-                               // that test, dot(centre, cone axis) + cone sin * widened radius (see filter_sphere_2)
+                               // that test (rt_prep.h cone_constant)
+  f3 centre;                   // the scene centre the filter records are relative to
   const f4 * camtab;           // n_padded x (centre - camera, filter bound): the primary-ray filter
   const uint32_t * sphere_mat; // n_spheres
   const f4 * materials;        // n_materials x RT_MAT_RECORDS: (albedo rgb, roughness), (refraction, type bits,
@@ -816,25 +822,52 @@ struct ShadowCone
   float oa;      // one-light kernels: dot(origin of the pass, axis) / cos_m, lowered by its own rounding error
 };
 
-// One sphere against the shadow cone and the scattered ray of a pass (common origin o).  Both tests are taken in
-// squared form, so that no square root is needed per sphere: with b2 = |d|^2 (1 - m) - rw^2, the square of
-// filter_bound's value (negative for an origin inside the widened sphere, where filter_bound gives 0),
+// What a shade pass knows about its origin O and its scattered ray D before it meets the spheres.
+struct ShadeOrigin
+{
+  f3 o;       // O' = O - scene centre
+  f3 a;       // 2 (1 - m) O'
+  float p;    // (RT_FILTER_SLACK - (1 - m)) |O'|^2
+  f3 dir;     // D
+  float nod;  // -dot(O', D)
+};
+
+RT_FN ShadeOrigin shade_origin(f3 o, f3 centre, f3 dir)
+{
+  ShadeOrigin F;
+  F.o = o - centre;
+  float const twice = (float)(2.0 * (1.0 - RT_FILTER_MARGIN));
+  F.a = mk3(F.o.x * twice, F.o.y * twice, F.o.z * twice);
+  F.p = (float)(RT_FILTER_SLACK - (1.0 - RT_FILTER_MARGIN)) * fdot3(F.o, F.o);
+  F.dir = dir;
+  F.nod = -fdot3(F.o, dir);
+  return F;
+}
+
+// One sphere against the shadow cone and the scattered ray of a pass (common origin O).  Both tests are taken in
+// squared form, so that no square root is needed per sphere: with d = C - O and b2 = |d|^2 (1 - m) - rw^2, the
+// square of filter_bound's value (negative for an origin inside the widened sphere, where filter_bound gives 0),
 //   ray   u = dot(d, D) >= sqrt(b2)                  <=>  u >= 0 and u^2 >= b2           <=>  u |u| - b2 >= 0
 //   cone  s = dot(d, axis) + sin rw >= cos sqrt(b2)  <=>  s >= 0 and s^2 >= cos^2 b2     <=>  s |s| - cos^2 b2 >= 0
-// (for b2 < 0 the right-hand forms accept a little more than u >= 0 and s >= 0: the safe side).  Squaring costs a
-// rounding of a few 1e-8 of |d|^2, which the margin m covers many times over.
-// s.w holds rw^2.  aux: rw, or -- kKnownCone, kernels whose one light is known when the scene is made -- the part
-// of s / cos that depends on the sphere alone, (dot(C, axis) + sin rw) / cos, raised by the rounding error it and
-// the subtraction below can have (rt_prep.h cone_constant); s / cos is then one subtraction, of cone.oa =
-// dot(o, axis) / cos, and the test reads (s / cos) |s / cos| - b2 >= 0.
+// (for b2 < 0 the right-hand forms accept a little more than u >= 0 and s >= 0: the safe side).
+// Neither needs d itself.  With C' and O' relative to the scene centre,
+//   -b2 = [rw^2 - (1 - m) |C'|^2] + dot(C', 2 (1 - m) O') - (1 - m) |O'|^2,      u = dot(C', D) - dot(O', D):
+// a sphere's record is (C', its bracket), a pass brings 2 (1 - m) O', its own last term and -dot(O', D), and a
+// sphere costs two chains of three FMAs and an addition where the offset, its square and the bound took seven
+// instructions before the ray was looked at.  The products are as large as the points are far from the centre, so
+// their rounding (under 2.2e-6 (|C'|^2 + |O'|^2) for both tests together) is not covered by m |d|^2; the bracket
+// and the pass's term each carry RT_FILTER_SLACK times their squared distance instead (rt_prep.h flatten_scene,
+// shade_origin): the filter lets through a little more for a scene far from its own centre, never less.
+// aux: rw, or -- kKnownCone, kernels whose one light is known when the scene is made -- the part of s / cos that
+// depends on the sphere alone, (dot(C', axis) + sin rw) / cos, raised by the rounding error it and the subtraction
+// below can have (rt_prep.h cone_constant); s / cos is then one subtraction, of cone.oa = dot(O', axis) / cos, and
+// the test reads (s / cos) |s / cos| - b2 >= 0.
 template <bool kKnownCone>
-RT_FN void filter_sphere_2(f4 s, float aux, f3 o, const ShadowCone & cone, f3 sdir, uint32_t & cone_mask,
+RT_FN void filter_sphere_2(f4 s, float aux, const ShadeOrigin & F, const ShadowCone & cone, uint32_t & cone_mask,
                            uint32_t & ray_mask)
 {
-  float const dx = s.x - o.x, dy = s.y - o.y, dz = s.z - o.z;
-  float const dd = hw_fma(dz, dz, hw_fma(dy, dy, dx * dx));
-  float const nb2 = hw_fma(dd, -(float)(1.0 - RT_FILTER_MARGIN), s.w);  // -b2
-  float const u = hw_fma(dz, sdir.z, hw_fma(dy, sdir.y, dx * sdir.x));
+  float const nb2 = hw_fma(s.z, F.a.z, hw_fma(s.y, F.a.y, hw_fma(s.x, F.a.x, s.w))) + F.p;  // -b2
+  float const u = hw_fma(s.z, F.dir.z, hw_fma(s.y, F.dir.y, hw_fma(s.x, F.dir.x, F.nod)));
   ray_mask = push_sign(ray_mask, hw_fma(u, hw_abs(u), nb2));
   if constexpr (kKnownCone)
   {
@@ -843,6 +876,7 @@ RT_FN void filter_sphere_2(f4 s, float aux, f3 o, const ShadowCone & cone, f3 sd
   }
   else
   {
+    float const dx = s.x - F.o.x, dy = s.y - F.o.y, dz = s.z - F.o.z;
     float const sc = hw_fma(dz, cone.axis.z, hw_fma(dy, cone.axis.y, hw_fma(dx, cone.axis.x, cone.sin_m * aux)));
     cone_mask = push_sign(cone_mask, hw_fma(sc, hw_abs(sc), cone.cos2_m * nb2));
   }
@@ -850,8 +884,8 @@ RT_FN void filter_sphere_2(f4 s, float aux, f3 o, const ShadowCone & cone, f3 sd
 
 // The shadow cone and the scattered ray against `count` (<= RT_CHUNK) spheres.
 template <uint32_t kUnroll, bool kKnownCone>
-RT_FN void filter_chunk_2(const f4 * sph, const float * aux, uint32_t count, f3 o, const ShadowCone & cone, f3 sdir,
-                          uint32_t & cone_mask, uint32_t & ray_mask)
+RT_FN void filter_chunk_2(const f4 * sph, const float * aux, uint32_t count, const ShadeOrigin & F,
+                          const ShadowCone & cone, uint32_t & cone_mask, uint32_t & ray_mask)
 {
   cone_mask = 0;
   ray_mask = 0;
@@ -860,10 +894,10 @@ RT_FN void filter_chunk_2(const f4 * sph, const float * aux, uint32_t count, f3 
   {
 #pragma unroll
     for (uint32_t u = 0; u < kUnroll; ++u)
-      filter_sphere_2<kKnownCone>(sph[j + u], aux[j + u], o, cone, sdir, cone_mask, ray_mask);
+      filter_sphere_2<kKnownCone>(sph[j + u], aux[j + u], F, cone, cone_mask, ray_mask);
   }
   for (; j < count; ++j)
-    filter_sphere_2<kKnownCone>(sph[j], aux[j], o, cone, sdir, cone_mask, ray_mask);
+    filter_sphere_2<kKnownCone>(sph[j], aux[j], F, cone, cone_mask, ray_mask);
   cone_mask = chunk_candidates(cone_mask, count);
   ray_mask = chunk_candidates(ray_mask, count);
 }
@@ -1127,7 +1161,7 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
 // rays_on: bit r set if ray r of this lane is to be traced.  Returns the shadow rays found occluded as bits
 // 0..4; the nearest hit of the scattered ray (ray 5) goes to near_t / near_i.  `cone` holds dir[0..4].
 template <bool kGrid, bool kOneLight, class Env>
-RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], const ShadowCone & cone, uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
+RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[RT_RAYS], ShadowCone cone, uint32_t rays_on, float & near_t, int & near_i, LaneCounters & cnt)
 {
   if constexpr (kGrid)
   {
@@ -1146,6 +1180,17 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
   }
   uint32_t live = rays_on;  // rays still looking for a hit
   bool const library_math = Env::kLibraryMath;
+  ShadeOrigin const F = shade_origin(o, A.centre, dir[RT_RAYS - 1]);
+  cone.cos2_m = cone.cos_m * cone.cos_m;
+  cone.oa = 0.0f;
+  if constexpr (kOneLight)
+  {
+    // dot(O', axis) / cos, lowered by several times the rounding error its operations can have (three for the dot
+    // product, the rounding of 1 / cos and the last multiplication: 6e-8 of the terms' sizes each)
+    float const l1 = hw_fma(hw_abs(F.o.z), hw_abs(cone.axis.z),
+                            hw_fma(hw_abs(F.o.y), hw_abs(cone.axis.y), hw_abs(F.o.x) * hw_abs(cone.axis.x)));
+    cone.oa = hw_fma(-8e-7f, l1, fdot3(F.o, cone.axis)) * A.cone_inv_cos;
+  }
   near_i = -1;
   near_t = 0.0f;
   constexpr uint32_t kShadowRays = (1u << RT_LIGHT_SAMPLES) - 1u;
@@ -1166,10 +1211,10 @@ RT_FN uint32_t trace_pass(const TraceArgs & A, Env & env, f3 o, const f3 (&dir)[
       uint32_t const count_hi = (rest < RT_CHUNK) ? rest : RT_CHUNK;
       uint32_t cone_lo, ray_lo, cone_hi = 0u, ray_hi = 0u;
       RT_REGION(cnt, 6);
-      filter_chunk_2<Env::kFilterUnroll, kOneLight>(sph + c0, aux + c0, count_lo, o, cone, dir[RT_RAYS - 1], cone_lo, ray_lo);
+      filter_chunk_2<Env::kFilterUnroll, kOneLight>(sph + c0, aux + c0, count_lo, F, cone, cone_lo, ray_lo);
       if (count_hi != 0u)
-        filter_chunk_2<Env::kFilterUnroll, kOneLight>(sph + c0 + RT_CHUNK, aux + c0 + RT_CHUNK, count_hi, o, cone,
-                                                      dir[RT_RAYS - 1], cone_hi, ray_hi);
+        filter_chunk_2<Env::kFilterUnroll, kOneLight>(sph + c0 + RT_CHUNK, aux + c0 + RT_CHUNK, count_hi, F, cone, cone_hi,
+                                                      ray_hi);
       RT_REGION(cnt, 7);
       // sphere j of the group in bit 63 - j: the lowest index is the highest bit
       unsigned long long cone_mask = group_mask(cone_lo, count_lo, cone_hi, count_hi);
@@ -1512,16 +1557,6 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       rays_on |= (in_pass && L.li == 0u) ? (1u << (RT_RAYS - 1)) : 0u;
     }
 
-    cone.cos2_m = cone.cos_m * cone.cos_m;
-    cone.oa = 0.0f;
-    if constexpr (kOneLight)
-    {
-      // dot(hit point, axis) / cos, lowered by several times the rounding error its operations can have (three
-      // for the dot product, the rounding of 1 / cos and the last multiplication: 6e-8 of the terms' sizes each)
-      float const l1 = hw_fma(hw_abs(L.hp.z), hw_abs(cone.axis.z),
-                              hw_fma(hw_abs(L.hp.y), hw_abs(cone.axis.y), hw_abs(L.hp.x) * hw_abs(cone.axis.x)));
-      cone.oa = hw_fma(-8e-7f, l1, fdot3(L.hp, cone.axis)) * A.cone_inv_cos;
-    }
     float near_t;
     int near_i;
     RT_REGION(cnt, 9);

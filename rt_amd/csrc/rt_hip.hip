@@ -570,8 +570,8 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
 // Per-launch set-up in one small kernel: the primary-ray filter table -- per sphere, (centre - camera, filter
 // bound) -- and the words a trace starts from zero (its counters and queue word, the split-record count).
 // One thread per table entry, at least one block.
-__global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ filter, f4 * __restrict__ camtab,
-                                                     uint32_t n_padded, f3 cam_pos, float col_delta,
+__global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ spheres, const float * __restrict__ aux_rw,
+                                                     f4 * __restrict__ camtab, uint32_t n_padded, f3 cam_pos, float col_delta,
                                                      unsigned long long * __restrict__ stats, uint32_t stats_words,
                                                      uint32_t * __restrict__ split_count)
 {
@@ -582,7 +582,8 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
     *split_count = 0u;
   if (i >= n_padded)
     return;
-  f4 const s = filter[i];
+  f4 const s = spheres[i];
+  float const rw = aux_rw[i];  // the radius widened by the filter margin
   float const dx = s.x - cam_pos.x, dy = s.y - cam_pos.y, dz = s.z - cam_pos.z;
   f4 e;
   e.x = dx;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void camtab_kernel(const f4 * __restrict__ fil
   e.z = dz;
   // With column masks the bound is lowered by |d| * col_delta (rounded up), see TraceArgs::col_delta.
   float const len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f;
-  e.w = filter_bound(dx, dy, dz, s.w) - len * col_delta;
+  e.w = filter_bound(dx, dy, dz, rw * rw) - len * col_delta;
   camtab[i] = e;
 }
 
@@ -809,6 +810,7 @@ struct rt_hip_scene
   uint32_t n_spheres = 0, n_padded = 0, n_materials = 0, n_lights = 0;
   bool forward_ok = false;  // paths can be accumulated forward (rt_prep.h forward_accumulation_ok)
   ShadowCone cone0;         // shadow cone of light 0 (kernels specialised for one light take it as an argument)
+  f3 centre = {0.0f, 0.0f, 0.0f};  // what the filter records are relative to (rt_prep.h flatten_scene)
   bool in_bounds = false;   // the sizes rt_core.h near_root and inv_sqrt_rn ask for: centres within 2^40 of the origin,
                             // radii and light vectors between 2^-40 and 2^40 long, roughness at most 2^40
   // Blocks per compute unit of the trace kernel this scene is traced with, asked of the runtime once per kernel
@@ -1093,6 +1095,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.filter = scene->d_filter;
   a.aux_rw = scene->d_aux_rw;
   a.aux_cone = scene->d_aux_cone;
+  a.centre = scene->centre;
   a.camtab = d_camtab;
   a.sphere_mat = scene->d_sphere_mat;
   a.materials = scene->d_materials;
@@ -1155,7 +1158,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   {
     int const tab_blocks = std::max(1, (int)((scene->n_padded + 255u) / 256u));
-    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_filter, d_camtab,
+    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_spheres, scene->d_aux_rw, d_camtab,
                        scene->n_padded, a.cam_pos, a.col_delta, d_stats, (uint32_t)(kStatsWords + 1), a.split_count);
     RT_CHECK(hipGetLastError());
   }
@@ -1486,6 +1489,7 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
   s->n_padded = static_cast<uint32_t>(fs.spheres.size());
   s->n_materials = material_count;
   s->n_lights = light_count;
+  s->centre = fs.centre;
   s->cone0 = shadow_cone(light_count ? lights[0].direction : nullptr, light_count != 0u && !cones_disabled());
   s->in_bounds = true;
   for (size_t k = 0; k < 4u * (size_t)sphere_count; ++k)

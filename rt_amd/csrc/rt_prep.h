@@ -224,9 +224,11 @@ inline void build_grid(const float * centers_radii, uint32_t n, GridHost & g)
 struct FlatScene
 {
   std::vector<f4> spheres;           // (cx, cy, cz, r*r)
-  std::vector<f4> filter;            // (cx, cy, cz, square of the radius widened by the filter margin)
-  std::vector<float> aux_rw;         // the widened radius
+  std::vector<f4> filter;            // (centre - scene centre, rw^2 - (1 - m - slack) |centre - scene centre|^2): the
+                                     // shade filter's record of a sphere, rt_core.h filter_sphere_2
+  std::vector<float> aux_rw;         // the widened radius rw
   std::vector<float> aux_cone;       // cone_constant of the sphere for the first light's shadow cone
+  f3 centre;                         // the scene centre: mean centre of the spheres of ordinary size
   std::vector<uint32_t> sphere_mat;  // material index per sphere
   std::vector<f4> materials;         // RT_MAT_RECORDS per material
   std::vector<f4> lights;            // RT_LIGHT_RECORDS per light
@@ -267,7 +269,7 @@ inline ShadowCone shadow_cone(const float * light_direction, bool use_cone)
 // than the rounding errors of storing it and of that subtraction (each at most 6e-8 of the terms' magnitudes): the
 // test stays on the accepting side.  The cone that holds every direction gets a value no subtraction brings below
 // zero.
-inline float cone_constant(const float * centre, float rw, const ShadowCone & cone)
+inline float cone_constant(const double * centre, float rw, const ShadowCone & cone)
 {
   if (!(cone.sin_m < 1e30f) || !(cone.cos_m > 0.0f))
     return 3.0e38f;
@@ -299,6 +301,33 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
   out.aux_rw.resize(n);
   out.aux_cone.resize(n);
   ShadowCone const cone0 = shadow_cone(l != 0u ? lights[0].direction : nullptr, shadow_cones);
+  // The scene centre: the mean centre of the spheres no more than sixteen times the median radius (a ground sphere
+  // of radius 1000 says nothing about where the scene is), as a float vector, since the kernel subtracts it from
+  // its origins in float.
+  out.centre = mk3(0.0f, 0.0f, 0.0f);
+  if (n != 0u)
+  {
+    std::vector<float> radii(n);
+    for (uint32_t i = 0; i < n; ++i)
+      radii[i] = std::fabs(centers_radii[4u * i + 3u]);
+    std::nth_element(radii.begin(), radii.begin() + n / 2u, radii.end());
+    double const limit = 16.0 * radii[n / 2u];
+    double sum[3] = {0.0, 0.0, 0.0};
+    uint32_t used = 0;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      const float * s = centers_radii + 4u * i;
+      if (std::fabs(s[3]) <= limit && std::isfinite(s[0]) && std::isfinite(s[1]) && std::isfinite(s[2]))
+      {
+        sum[0] += s[0];
+        sum[1] += s[1];
+        sum[2] += s[2];
+        used += 1u;
+      }
+    }
+    if (used != 0u)
+      out.centre = mk3((float)(sum[0] / used), (float)(sum[1] / used), (float)(sum[2] / used));
+  }
   out.sphere_mat.assign(material_index, material_index + n);
   for (uint32_t i = 0; i < n; ++i)
   {
@@ -308,10 +337,17 @@ inline void flatten_scene(const float * centers_radii, const uint32_t * material
     // the widened radius, rounded up, and its square, rounded up
     double const widened = std::fabs(static_cast<double>(s[3])) * (1.0 + RT_FILTER_MARGIN);
     float const rw = std::max(std::nextafter(static_cast<float>(widened), INFINITY), 1e-30f);
-    float const rw2 = std::nextafter(static_cast<float>((double)rw * rw), INFINITY);
-    out.filter[i] = mk4(s[0], s[1], s[2], rw2);
+    // the sphere relative to the scene centre (the differences of two floats, exact in double, rounded once) and
+    // its constant rw^2 - (1 - m) |C'|^2 + slack |C'|^2, taken from the rounded C' the kernel multiplies with and
+    // rounded up
+    double const cd[3] = {(double)s[0] - out.centre.x, (double)s[1] - out.centre.y, (double)s[2] - out.centre.z};
+    float const cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+    double const cc = (double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2];
+    double const q = (double)rw * rw - (1.0 - RT_FILTER_MARGIN - RT_FILTER_SLACK) * cc;
+    out.filter[i] = mk4(cf[0], cf[1], cf[2], std::nextafter(static_cast<float>(q), INFINITY));
     out.aux_rw[i] = rw;
-    out.aux_cone[i] = cone_constant(s, rw, cone0);
+    double const cfd[3] = {cf[0], cf[1], cf[2]};
+    out.aux_cone[i] = cone_constant(cfd, rw, cone0);
   }
   // Per-material constants of Scatter and GetSpecular, computed here once with the float operations the
   // reference uses per hit (ray_tracing/default_materials.cpp:30,50,61-62; directional_light.cpp:49-56).

@@ -154,10 +154,10 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   std::vector<rtc::f4> camtab(padded);
   for (uint32_t i = 0; i < padded; ++i)
   {
-    float const dx = fs.filter[i].x - a.cam_pos.x, dy = fs.filter[i].y - a.cam_pos.y,
-                dz = fs.filter[i].z - a.cam_pos.z;
+    float const dx = fs.spheres[i].x - a.cam_pos.x, dy = fs.spheres[i].y - a.cam_pos.y,
+                dz = fs.spheres[i].z - a.cam_pos.z;
     float const len = std::sqrt(dx * dx + dy * dy + dz * dz) * 1.000001f;
-    camtab[i] = rtc::mk4(dx, dy, dz, rtc::filter_bound(dx, dy, dz, fs.filter[i].w) - len * a.col_delta);
+    camtab[i] = rtc::mk4(dx, dy, dz, rtc::filter_bound(dx, dy, dz, fs.aux_rw[i] * fs.aux_rw[i]) - len * a.col_delta);
   }
   std::vector<float> jitter(rtc::RT_JITTER_FLOATS);
   rtc::build_jitter_table(jitter.data());
@@ -166,6 +166,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
   a.filter = fs.filter.data();
   a.aux_rw = fs.aux_rw.data();
   a.aux_cone = fs.aux_cone.data();
+  a.centre = fs.centre;
   a.camtab = camtab.data();
   a.n_padded = padded;
   a.sphere_mat = fs.sphere_mat.data();
