@@ -47,6 +47,29 @@ def random_scene(k, offset=(0.0, 0.0, 0.0)):
                                                         background=(0.8, 0.85, 0.9)))
 
 
+def split_scene(k, gap):
+    """Two groups of small spheres `gap` apart with the camera between them and to the side, looking across both: the
+    scene's centre lies in the empty middle, so every sphere and every hit point is far from it -- where the shade
+    filter's products are large against the distances that decide a hit."""
+    g = np.random.default_rng(2000 + k)
+    mats = [(0, (0.6, 0.6, 0.6), 0.7, 0.0)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0)]
+    for side in (-0.5, 0.5):
+        for _ in range(int(g.integers(8, 25))):
+            kind = int(g.integers(0, 3))
+            mats.append((kind, tuple(float(x) for x in g.uniform(0.1, 1.0, 3)), float(g.uniform(0.0, 0.9)) if kind == 1 else 0.7,
+                         float(g.uniform(0.8, 0.9)) if kind == 2 else float(g.uniform(0.0, 0.2))))
+            rad = float(g.uniform(0.1, 0.5)) * max(1.0, gap / 400.0)
+            spheres.append((side * gap + float(g.uniform(-3, 3)) * max(1.0, gap / 400.0), rad - 1.0 + float(g.uniform(0, 1.5)),
+                            float(g.uniform(-3, 3)) * max(1.0, gap / 400.0), rad, len(mats) - 1))
+    d = g.normal(size=3)
+    d[1] = -abs(d[1]) - 0.5
+    d /= np.linalg.norm(d)
+    lights = [(tuple(float(x) for x in d), (0.9, 0.9, 0.8))]
+    return ffi.Scene.build(spheres, mats, lights, dict(position=(-0.5 * gap - 8.0 * max(1.0, gap / 400.0), 1.5, -6.0 * max(1.0, gap / 400.0)),
+                                                        direction=(0.98, -0.05, 0.2), background=(0.8, 0.85, 0.9)))
+
+
 def without_cones(make):
     os.environ["RT_HIP_NO_CONES"] = "1"
     try:
@@ -60,7 +83,8 @@ def without_cones(make):
 makers = [lambda: ffi.Scene.demo(1, 1), lambda: ffi.Scene.demo(2, 1), lambda: ffi.Scene.demo(3, 1, 100),
           lambda: ffi.Scene.demo(3, 1, 700)] + [(lambda k=k: random_scene(k)) for k in range(8)] + [
     (lambda k=k, o=o: random_scene(k, o)) for k, o in ((8, (30.0, -20.0, 50.0)), (9, (-300.0, 200.0, 100.0)), (10, (1000.0, 3000.0, -2000.0)),
-                                                       (11, (-2e4, 1e4, 3e4)))]
+                                                       (11, (-2e4, 1e4, 3e4)))] + [
+    (lambda k=k, gap=gap: split_scene(k, gap)) for k, gap in ((0, 60.0), (1, 200.0), (2, 900.0), (3, 3000.0))]
 scenes = [m() for m in makers]
 plain = [without_cones(m) for m in makers]
 cases = worst = 0
