@@ -46,12 +46,12 @@ PEAK_VALU_LANE_OPS = 78.64e12    # ... of which one vector instruction per lane 
 # Vector instructions per unit of work, counted in the kernel's ISA and fitted to SQ_INSTS_VALU of the profiled
 # workloads (the model lands within 2.5 % of the counter on all five): what the executed-work model multiplies the
 # device counters with for workloads that have no committed counter profile.
-INSTR_SHADE_SPHERE = 16.5  # one sphere in a shade pass: offset, squared bound, shadow cone test, scattered-ray test (15) + loop
+INSTR_SHADE_SPHERE = 13.5  # one sphere in a shade pass: squared bound, ray projection, the two tests (12) + loop
 INSTR_PRIMARY_TEST = 4.5   # one camera-table entry against one direction (3 FMA + the mask shift) + loop
 INSTR_CONE_SPHERE = 40     # one sphere the cone touched: its record, offset and c, loop bookkeeping
 INSTR_EXACT_TEST = 25      # one exact intersection (b, discriminant, short correctly rounded sqrt and quotient, range tests)
-INSTR_SHADED_BOUNCE = 725  # scatter, specular, two Philox blocks, six ray set-ups, light sum, path bookkeeping
-INSTR_SAMPLE = 422         # a primary round: primary direction, item bookkeeping, hit set-up, share of column preparation
+INSTR_SHADED_BOUNCE = 678  # scatter, specular, two Philox blocks, six ray set-ups, light sum, path bookkeeping
+INSTR_SAMPLE = 470         # a primary round: primary direction, item bookkeeping, hit set-up, share of column preparation
 
 
 def algorithmic_flop(stats, n_spheres):
