@@ -13,14 +13,18 @@
 //   trace_kernel_grid    the same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).
 //   fold_kernel          completes the sums of columns whose last samples were traced by other lanes of the
 //                        owner's wave (sample sharing at the end of the queue).
-//   colsum_kernel        accumulate pass: per pixel, its column sums -> planar pixel sums.
+//   trace_kernel<*, *, false, true>  the kernels for any number of lights built with the compiler's general IEEE
+//                        square root and division (scenes outside the bounds of the short sequences).
+//   colsum_kernel        accumulate pass: per pixel, its column sums -> planar pixel sums (a lane per pixel).
+//   colsum_lds_kernel    the same for the common sample counts: whole-line loads, transposed through LDS.
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
-//                        16 bytes per lane per access.  These two are the HBM-bound passes.
+//                        16 bytes per lane per access.  These are the HBM-bound passes.
+//   exact_math_check_kernel  self-check of the short correctly rounded sequences (rt_hip_check_exact_math).
 //
 //   camtab_kernel        per-launch set-up: table of the primary-ray filter (one entry per sphere), counters reset.
 //
-// LDS per block: the resident scene (48 B per sphere, material and light) and 8 KB of prepared
-// columns, or one 16 KB staging tile for scenes above kResidentSpheres spheres.
+// LDS per block: the resident scene (56 B per sphere, 48 B per material and light) and 8 KB of prepared
+// columns, or one 20 KB staging tile for scenes above kResidentSpheres spheres.
 #include "rt_core.h"
 #include "rt_hip.h"
 #include "rt_prep.h"
