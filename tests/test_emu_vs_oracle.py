@@ -261,3 +261,39 @@ def test_shadow_cones_change_no_bit(ffi, scenes, demo, spheres):
         assert sa["exact_tests"] < sb["exact_tests"]
         sa.pop("exact_tests"), sb.pop("exact_tests")
         assert sa == sb
+
+
+def _two_groups(ffi, gap, seed):
+    """Two groups of small spheres `gap` apart, the camera beside one looking across both: every sphere and every
+    hit point is far from the scene's centre, which lies in the empty middle."""
+    g = np.random.default_rng(seed)
+    scale = max(1.0, gap / 400.0)
+    mats = [(0, (0.6, 0.6, 0.6), 0.7, 0.0)]
+    spheres = [(0.0, -1001.0, 0.0, 1000.0, 0)]
+    for side in (-0.5, 0.5):
+        for _ in range(12):
+            kind = int(g.integers(0, 3))
+            mats.append((kind, tuple(float(x) for x in g.uniform(0.1, 1.0, 3)), float(g.uniform(0.0, 0.9)) if kind == 1 else 0.7,
+                         float(g.uniform(0.8, 0.9)) if kind == 2 else float(g.uniform(0.0, 0.2))))
+            rad = float(g.uniform(0.1, 0.5)) * scale
+            spheres.append((side * gap + float(g.uniform(-3, 3)) * scale, rad - 1.0 + float(g.uniform(0, 1.5)),
+                            float(g.uniform(-3, 3)) * scale, rad, len(mats) - 1))
+    lights = [((0.3, -0.9, 0.2), (0.9, 0.9, 0.8))]
+    return ffi.Scene.build(spheres, mats, lights, dict(position=(-0.5 * gap - 8.0 * scale, 1.5, -6.0 * scale),
+                                                        direction=(0.98, -0.05, 0.2), background=(0.8, 0.85, 0.9)))
+
+
+@pytest.mark.parametrize("gap", [60.0, 900.0, 3000.0])
+def test_shade_filter_far_from_the_scene_centre(oracle, ffi, gap):
+    """The shade filter multiplies scene-centred coordinates of sphere and hit point; where both are large against
+    the distance between them its explicit slack has to cover the rounding.  Same hits as the brute-force oracle."""
+    scene = _two_groups(ffi, gap, 7)
+    for depth in (1, 0):
+        p = ffi.params(64, 36, 2, flags=ffi.FLAG_DETERMINISTIC, max_depth=depth)
+        ref, rs = oracle.render(scene, p, 8)
+        for forward in (False, True):
+            out, es = emu_ffi.render(scene, p, column_masks=True, forward=forward)
+            assert rel_err(ref, out).max() < 1e-5
+            for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces"):
+                assert es[key] == getattr(rs, key), key
+    assert rs.hit_queries > 0.1 * rs.samples  # the spheres are in view
