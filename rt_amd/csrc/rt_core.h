@@ -13,16 +13,17 @@
 //
 // Ray against all spheres, in two steps:
 //   filter   a ray from O along unit D can only hit sphere (C, r) in front of O if
-//            dot(C - O, D) >= sqrt(|O - C|^2 - r^2).  The right-hand side depends on the origin only, so
-//            it is computed once per sphere for the rays of a pass (and once per frame for the camera); a
-//            ray-sphere test is then 3 FMAs and one instruction that shifts the sign of the result into a
-//            per-lane candidate mask.  A small margin keeps the filter conservative.  The five shadow rays
-//            of a light all lie in a narrow cone around the direction to the light, so a pass tests that
-//            cone once per sphere (same cost as one ray) and only the spheres the cone may touch go on to
-//            the exact intersection, for the five rays at once.
+//            dot(C - O, D) >= sqrt(|O - C|^2 - r^2).  For primary rays the right-hand side is a per-frame table
+//            (one origin: the camera) and a ray-sphere test is 3 FMAs and one instruction that shifts the sign
+//            of the result into a per-lane candidate mask.  A shade pass takes the test in squared form, from
+//            products of scene-centred coordinates of sphere and origin, without forming C - O (filter_sphere_2).
+//            A small margin keeps the filter conservative.  The five shadow rays of a light all lie in a narrow
+//            cone around the direction to the light, so a pass tests that cone once per sphere (cheaper than
+//            one ray) and only the spheres the cone may touch go on to the exact intersection, for the five
+//            rays at once.
 //   resolve  the few candidates are intersected exactly as Sphere::TraceNearest does
-//            (ray_tracing/sphere.cpp:63-81), operation for operation, with IEEE sqrt and division and
-//            without FMA contraction, keeping the nearest one as TraceNearestInHitableCollection does
+//            (ray_tracing/sphere.cpp:63-81), operation for operation, with correctly rounded sqrt and division
+//            (near_root) and without FMA contraction, keeping the nearest one as TraceNearestInHitableCollection does
 //            (ray_tracing/hitable_object.hpp:71-87).  Shadow rays stop at their first accepted hit.
 // Everything downstream of a hit (hit point, normal, scatter, specular, accumulation) uses the same
 // un-contracted IEEE operations as the CPU path, so the only approximate arithmetic is in the filter,
