@@ -133,6 +133,9 @@ RT_FN int hw_clz64(unsigned long long x) { return __clzll((long long)x); }
 RT_FN uint32_t f2u(float f) { return __float_as_uint(f); }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
 RT_FN float hw_abs(float a) { return __builtin_fabsf(a); }
+RT_FN float hw_min(float a, float b) { return fminf(a, b); }
+// clamp as one instruction (the median of three); equal to min(max(x, lo), hi) for every x that is not a NaN
+RT_FN float hw_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 // mask = 2 * mask + (the sign bit of x): one v_alignbit_b32.
 RT_FN uint32_t push_sign(uint32_t mask, float x) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(x), 31u); }
 #else
@@ -156,6 +159,8 @@ RT_FN uint32_t f2u(float f)
 }
 RT_FN float hw_max(float a, float b) { return fmaxf(a, b); }
 RT_FN float hw_abs(float a) { return fabsf(a); }
+RT_FN float hw_min(float a, float b) { return fminf(a, b); }
+RT_FN float hw_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 RT_FN uint32_t push_sign(uint32_t mask, float x) { return (mask << 1) | (f2u(x) >> 31); }
 #endif
 
@@ -294,7 +299,7 @@ RT_FN f3 jitter_ball(const float * tab, uint32_t k1, uint32_t k2, uint32_t k3)
 RT_FN f3 ball3(float radius, float u1, float u2, float u3)
 {
   float const z = 1.0f - 2.0f * u1;
-  float const s = hw_sqrt(maxf(0.0f, 1.0f - z * z));
+  float const s = hw_sqrt(hw_max(0.0f, 1.0f - z * z));
   float const rad = radius * hw_exp2(hw_log2(u3) * (1.0f / 3.0f));
   return mk3((s * hw_cos_rev(u2)) * rad, (s * hw_sin_rev(u2)) * rad, z * rad);
 }
@@ -687,20 +692,21 @@ RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & 
 
 // DirectionalLight::GetSpecular, ray_tracing/directional_light.cpp:37-60.  The half vector and the cosines are
 // computed exactly (the Beckmann exponent multiplies their rounding by up to 1 / 0.03^2); the three quotients
-// and the exponential behind them only scale the result and use the hardware reciprocal and exp2 (~1e-6).
+// and the exponential behind them only scale the result and use the hardware reciprocal and exp2 (~1e-6).  The
+// clamps and minima are the hardware's (one instruction each): the same values for every operand but a NaN.
 RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, const MaterialView & m, f3 rd, f3 n, bool library_math)
 {
-  float const vdn = clampf(dot3(-rd, n), 0.0f, 1.0f);
-  float const ndl = clampf(dot3(n, -ldir), 0.0f, 1.0f);
+  float const vdn = hw_clamp(dot3(-rd, n), 0.0f, 1.0f);
+  float const ndl = hw_clamp(dot3(n, -ldir), 0.0f, 1.0f);
   f3 const h = -normalize3(ldir + rd, library_math);
-  float const ndh = clampf(dot3(n, h), RT_EPS, 1.0f);
-  float const vdh = clampf(dot3(-rd, h), 0.0f, 1.0f);
-  float const g = (fabsf(vdh) >= RT_EPS) ? minf(1.0f, 2.0f * ndh * minf(vdn, ndl) * hw_rcp(vdh)) : 1.0f;
+  float const ndh = hw_clamp(dot3(n, h), RT_EPS, 1.0f);
+  float const vdh = hw_clamp(dot3(-rd, h), 0.0f, 1.0f);
+  float const g = (fabsf(vdh) >= RT_EPS) ? hw_min(1.0f, 2.0f * ndh * hw_min(vdn, ndl) * hw_rcp(vdh)) : 1.0f;
   float const ndh2 = ndh * ndh;
   float const q = (ndh2 - 1.0f) * hw_rcp(m.r2 * ndh2);
   float const dm = hw_exp2(q * 1.44269504088896340736f) * hw_rcp(m.four_r2 * ndh2 * ndh2);
   float const f = m.f2 + (1.0f - m.f2) * pow5(1.0f - vdn);
-  float const spec = clampf(g * dm * f, 0.0f, 1.0f);
+  float const spec = hw_clamp(g * dm * f, 0.0f, 1.0f);
   return mix3(lcol, albedo, 0.5f) * spec;
 }
 

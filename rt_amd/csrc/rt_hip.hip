@@ -71,7 +71,8 @@ constexpr uint32_t kResidentLights = 16;
 constexpr uint32_t kColumnMaskSpheres = 64;   // column masks: two 32-bit words per lane
 constexpr uint32_t kGridMinSpheres = 64;      // smaller scenes get no grid: testing every sphere is faster
 constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS whole (48 B per sphere)
-constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 16 KB of LDS per staged tile of filter records
+constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 20 KB of LDS per staged tile of filter records and cone terms
+constexpr uint32_t kTileSpheresStack = 768;  // ... 15 KB where the path stacks (40 KB) share the block's 64 KB
 constexpr uint32_t kStatsWords = 9;
 
 // ---- rt_hip_trace_device_static: the one entry point that allocates nothing ----
@@ -364,8 +365,8 @@ struct BlockEnv
 #endif
   static constexpr uint32_t kPrimaryUnroll = RT_BLOCK_PRIMARY_UNROLL;
   const TraceArgs & A;
-  f4 * tile;              // LDS: kTileSpheres entries
-  float * tile_cone;      // LDS: kTileSpheres cone terms, staged with the filter records
+  f4 * tile;              // LDS: kTileSpheres entries (kTileSpheresStack in the kernels with path stacks)
+  float * tile_cone;      // LDS: as many cone terms, staged with the filter records
   const float * aux_src;  // where those come from: A.aux_cone for the one-light kernel, else A.aux_rw
   const float * jitter;   // LDS: RT_JITTER_FLOATS
   ItemPool pool;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   if constexpr (kTiled)
   {
     __syncthreads();
-    BlockEnv<kLibMath> env{A, sph, reinterpret_cast<float *>(sph + kTileSpheres), kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool()};
+    BlockEnv<kLibMath> env{A, sph, reinterpret_cast<float *>(sph + (kForward ? kTileSpheres : kTileSpheresStack)), kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
@@ -898,7 +899,11 @@ bool is_tiled(const rt_hip_scene * sc)
   return sc->n_padded > kResidentSpheres || sc->n_materials > kResidentMaterials || sc->n_lights > kResidentLights ||
          resident_lds_bytes(sc) > g_lib.lds_per_block || forced_tile() != 0u;
 }
-uint32_t tile_size() { return forced_tile() ? forced_tile() : kTileSpheres; }
+uint32_t tile_size(const rt_hip_scene * sc)
+{
+  uint32_t const most = sc->forward_ok ? kTileSpheres : kTileSpheresStack;
+  return forced_tile() ? std::min(forced_tile(), most) : most;
+}
 bool uses_column_masks(const rt_hip_scene * sc)
 {
   return !is_tiled(sc) && sc->n_padded > 0u && sc->n_padded <= kColumnMaskSpheres;
@@ -912,7 +917,7 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
   if (uses_grid(sc, flags))
     return bytes;
   if (is_tiled(sc))
-    bytes += (sizeof(f4) + sizeof(float)) * (size_t)kTileSpheres;
+    bytes += (sizeof(f4) + sizeof(float)) * (size_t)(sc->forward_ok ? kTileSpheres : kTileSpheresStack);
   else
     bytes = resident_lds_bytes(sc);
   return std::max<size_t>(bytes, 16u);
@@ -1107,7 +1112,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.jitter_tab = g_lib.jitter_tab;
   a.n_spheres = scene->n_spheres;
   a.n_padded = scene->n_padded;
-  a.tile_size = tile_size();
+  a.tile_size = tile_size(scene);
   a.n_materials = scene->n_materials;
   a.n_lights = scene->n_lights;
   a.cone_axis = scene->cone0.axis;
@@ -1411,7 +1416,8 @@ int rt_hip_init(int device)
   g_lib.compute_units = prop.multiProcessorCount;
   g_lib.clock_khz = prop.clockRate;
   // 64 KB is what a block gets without raising the kernel's dynamic-LDS attribute; the tiled layout with path
-  // stacks (61 KB) fits it, and a resident scene that would not is traced through tiles instead.
+  // stacks (61 KB with tiles of kTileSpheresStack records) fits it, and a resident scene that would not is traced
+  // through tiles instead.
   g_lib.lds_per_block = std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536u, 65536u);
   std::snprintf(g_lib.name, sizeof(g_lib.name), "%s (%s)", prop.name, prop.gcnArchName);
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
