@@ -258,10 +258,20 @@ RT_FN u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 #pragma unroll
   for (int r = 0; r < 10; ++r)
   {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // both halves of a 32 x 32 -> 64 bit product from one instruction (v_mad_u64_u32 issues like v_mul_hi_u32
+    // alone; the compiler would take v_mul_hi_u32 and v_mul_lo_u32)
+    unsigned long long p0, p1;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "v"(c0), "v"(0xD2511F53u) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(c2), "v"(0xCD9E8D57u) : "vcc");
+    uint32_t const hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t const hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
     uint32_t const hi0 = hw_mulhi(0xD2511F53u, c0);
     uint32_t const lo0 = 0xD2511F53u * c0;
     uint32_t const hi1 = hw_mulhi(0xCD9E8D57u, c2);
     uint32_t const lo1 = 0xCD9E8D57u * c2;
+#endif
     c0 = hw_xor3(hi1, c1, k0);
     c1 = lo1;
     c2 = hw_xor3(hi0, c3, k1);
