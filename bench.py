@@ -75,6 +75,29 @@ def executed_lane_ops(stats, n_spheres, grid, column_masks):
             INSTR_SAMPLE * stats["lane_rounds"])
 
 
+def measured_issue_rates():
+    """The same fraction for loops of one instruction kind on this part, four waves on every SIMD of the chip, from
+    the committed run of tools/micro/valu_rate.hip (profiles/r2_valu_rate_256cu.txt): what `executed.frac` can reach
+    at all for code made of such instructions."""
+    import re
+
+    path = os.path.join(ROOT, "profiles", "r2_valu_rate_256cu.txt")
+    nominal_ns = 2.0 / 2.4  # a wave64 instruction every two cycles at 2.4 GHz
+    out = {}
+    try:
+        with open(path) as f:
+            for line in f:
+                m = re.match(r"(v_fma_f32 \(3 vgpr\)|v_fmac_f32_e32|v_alignbit_b32|v_rcp_f32)\s{2,}.*?([0-9.]+) ns per instruction", line)
+                if m:
+                    out[m.group(1).split(" ")[0] + "_loop_frac"] = round(nominal_ns / float(m.group(2)), 3)
+    except OSError:
+        return None
+    if not out:
+        return None
+    out["source"] = "profiles/r2_valu_rate_256cu.txt"
+    return out
+
+
 def profiled(workload_key):
     """What the committed rocprofv3 counter passes hold for this workload (profiles/traffic.json): HBM bytes per
     trace launch (FETCH_SIZE doubled as the gfx950 guide prescribes for wide reads, plus WRITE_SIZE) and the
@@ -383,6 +406,9 @@ def main():
                         "clock (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz); cannot exceed 1, unlike the algorithmic "
                         "credit of 20 FLOP per test, which the filter undercuts",
             })
+            reference = measured_issue_rates()
+            if reference:
+                executed["measured_reference"] = reference
         if args.grid:
             bound = "latency (grid walk; achieved/frac credit the brute-force test count and do not apply)"
         else:
