@@ -168,6 +168,26 @@ __global__ void __launch_bounds__(1024) rate_kernel(unsigned long long * out, in
 #define F(i) "v_sub_f32_e64 %" #i ", %" #i ", |%8|\n"
       asm volatile(REP8(F) : FLOATS : "v"(c));
 #undef F
+    } else if constexpr (kKind == 34) {
+#define F(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+      asm volatile(REP8(F) : FLOATS : "v"(m) : "s20", "s21");
+#undef F
+    } else if constexpr (kKind == 35) {   // every other instruction a select
+      asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_add_f32_e32 %1, %8, %1\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_add_f32_e32 %3, %8, %3\n"
+                   "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_add_f32_e32 %5, %8, %5\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_add_f32_e32 %7, %8, %7\n"
+                   : FLOATS : "v"(m) : "vcc");
+    } else if constexpr (kKind == 36) {   // one select in eight
+      asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_add_f32_e32 %1, %8, %1\n v_add_f32_e32 %2, %8, %2\n v_add_f32_e32 %3, %8, %3\n"
+                   "v_add_f32_e32 %4, %8, %4\n v_add_f32_e32 %5, %8, %5\n v_add_f32_e32 %6, %8, %6\n v_add_f32_e32 %7, %8, %7\n"
+                   : FLOATS : "v"(m) : "vcc");
+    } else if constexpr (kKind == 37) {   // a compare and a select that reads it, then six additions
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_add_f32_e32 %2, %8, %2\n v_add_f32_e32 %3, %8, %3\n"
+                   "v_add_f32_e32 %4, %8, %4\n v_add_f32_e32 %5, %8, %5\n v_add_f32_e32 %6, %8, %6\n v_add_f32_e32 %7, %8, %7\n"
+                   : FLOATS : "v"(m) : "vcc");
+    } else if constexpr (kKind == 38) {   // select by arithmetic: max
+#define F(i) "v_max_f32_e32 %" #i ", %8, %" #i "\n"
+      asm volatile(REP8(F) : FLOATS : "v"(m));
+#undef F
     } else if constexpr (kKind == 32 || kKind == 33) {
       // the shade filter's mix per 4 spheres: 4 ds_read_b128 + 2 ds_read2_b32 per 48 vector instructions (kind 33: without the reads)
       if constexpr (kKind == 32) {
@@ -264,6 +284,10 @@ int main(int argc, char ** argv)
   run<19>("v_ffbh_u32", d_out);
   run<23>("v_mov_b32", d_out);
   run<15>("v_cndmask_b32 vcc", d_out);
+  run<34>("v_cndmask_b32 sgpr pair", d_out);
+  run<35>("cndmask,add alternating", d_out);
+  run<36>("1 cndmask + 7 add", d_out);
+  run<37>("cmp, cndmask, 6 add", d_out);
   run<16>("v_cmp_lt_f32 vcc", d_out);
   run<17>("v_cmp_lt_f32 sgpr pair", d_out);
   run<33>("fmac, no LDS reads", d_out);
