@@ -1,7 +1,10 @@
 // Issue cost of the vector instructions the trace kernels are made of, with four waves on every SIMD (one block of
 // 1024 lanes per CU, held apart by its LDS allocation), as the trace kernels run.  Per instruction kind: a loop of
 // eight independent instructions; reported: shader cycles (s_memtime) per instruction and SIMD, the median over the
-// blocks, and the clock the blocks saw (s_memtime against the 100 MHz s_memrealtime).
+// blocks, the clock the blocks saw (s_memtime against the 100 MHz s_memrealtime) and the nanoseconds per instruction
+// and SIMD that follow.  argv[1]: blocks to launch (256 = the whole chip; fewer leave CUs idle, and the chip then
+// holds its clock and issues FMAs faster).  The kernel's own duration is not the figure to read: blocks that the
+// dispatcher puts on one CU run one after the other.
 // Build: hipcc --offload-arch=gfx950 -O2 -o valu_rate valu_rate.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
