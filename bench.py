@@ -174,6 +174,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-reduce", action="store_true",
                     help="one frame at a time on one stream (default: two frames in flight on two streams)")
+    ap.add_argument("--sample-slices", action="store_true",
+                    help="several GPUs: divide the frame by samples (every rank visits every column) instead of by "
+                         "runs of 64 pixels (a rank traces every sample of its pixels; the reduced frame then equals "
+                         "the one-GPU frame bit for bit)")
     ap.add_argument("--no-room", action="store_true",
                     help="several GPUs: do not leave block slots free for the RCCL reduce kernel")
     ap.add_argument("--rehearse", action="store_true",
@@ -218,7 +222,8 @@ def main():
     # and uses every slot.
     if distributed and not args.rehearse and not args.no_room:
         flags |= ffi.FLAG_LEAVE_ROOM
-    p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world)
+    by_runs = not args.sample_slices
+    p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world, pixel_runs=by_runs)
     full = ffi.params(w, h, s, seed=1, flags=flags)
 
     device = torch.device("cuda", local_rank)
@@ -287,7 +292,8 @@ def main():
     # The same frame one at a time (no overlap of frames, no flag that announces one): what a caller that needs
     # each image before it asks for the next would see.  Reported beside the headline, never as it.  Measured twice:
     # image left on the device, and downloaded into pinned host memory (rank 0; the whole-job metric with PCIe).
-    p_alone = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED), rank, world)
+    p_alone = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED), rank, world,
+                                    pixel_runs=by_runs)
     singles = max(2, min(args.steps, 5))
     pinned = torch.empty(w * h * 3, dtype=torch.float32, pin_memory=True) if rank == 0 else None
 
@@ -437,8 +443,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s %dx%d, %dx%d SSAA, %d spheres, samples sharded over %d GPU(s), RCCL sum-reduce"
-                            % (demo_name, w, h, s, s, scene.sphere_count, world),
+                "workload": "%s %dx%d, %dx%d SSAA, %d spheres, %s sharded over %d GPU(s), RCCL sum-reduce"
+                            % (demo_name, w, h, s, s, scene.sphere_count,
+                               "runs of 64 pixels" if (by_runs and distributed) else "samples", world),
                 "scene_seed": 1,
                 "render_seed": 1,
                 "max_depth": 10,

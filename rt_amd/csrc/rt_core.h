@@ -367,6 +367,12 @@ struct TraceArgs
   // slice traces the samples sy = first_sample(item), + slice_count, ... of every column.  The work queue is
   // the items in order; position k is item k.
   uint32_t * queue_counter;   // next queue position of this slice to hand out
+  // Slices by pixels instead of samples (optional, run_items = 0: off): the frame's items are dealt out in runs
+  // of run_items (a multiple of the 64-item window and of s_row: whole pixels) to run_stride slices in turn, this
+  // slice takes the runs run_first, run_first + run_stride, ... and traces every sample of their columns
+  // (slice_count is 1 then).  Its queue has queue_items positions; position k is item queue_item(A, k).
+  uint32_t queue_items;       // positions in this launch's queue (n_items without runs)
+  uint32_t run_items, run_stride, run_first;
   uint32_t batch_items;       // queue positions a wave reserves at a time ...
   uint32_t batch_min;         // ... and near the end of the queue (see rt_hip.hip ItemPool)
   uint32_t guide_waves;       // waves of the launch
@@ -512,6 +518,15 @@ RT_FN f3 primary_dir(const TraceArgs & A, float sdx, float dyp, uint32_t sy, boo
 
 // First sample (sy) of column `item` that this slice owns; >= s_row when it owns none.  The owner of sample
 // item * s_row + sy is that number modulo slice_count (slice_count < 65536, so the products below fit).
+// Item at queue position `pos` (see TraceArgs::run_items).
+RT_FN uint32_t queue_item(const TraceArgs & A, uint32_t pos)
+{
+  if (A.run_items == 0u)
+    return pos;
+  uint32_t const run = pos / A.run_items;
+  return (run * A.run_stride + A.run_first) * A.run_items + (pos - run * A.run_items);
+}
+
 RT_FN uint32_t first_sample(const TraceArgs & A, uint32_t item)
 {
   if (A.s_row_mod == 0u)

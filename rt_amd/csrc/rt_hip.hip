@@ -113,12 +113,14 @@ __device__ __forceinline__ void timeline_mark(uint32_t k)
 }
 #endif
 constexpr uint32_t kItemBatch = 64;
+constexpr uint32_t kRunPixels = 64;  // slices by pixels: pixels per run (its items: a multiple of kItemBatch)
 constexpr uint32_t kCancelPoll = 8;
 constexpr uint32_t kGuide = 16;
 
 struct ItemPool
 {
-  uint32_t next = 0, end = 0;  // the current window, wave-uniform
+  uint32_t next = 0, end = 0;  // the current window (queue positions), wave-uniform
+  uint32_t delta = 0;          // item of a position of the current window - that position (a window lies in one run)
   uint32_t reserved_end = 0;   // end of the wave's reservation
   uint32_t refills = 0;
   uint32_t last_size = 0;      // size of the wave's previous reservation
@@ -139,7 +141,7 @@ struct ItemPool
       if (A.batch_min < A.batch_items)
       {
         unsigned long long const seen = (unsigned long long)reserved_end + (unsigned long long)A.guide_waves * last_size;
-        unsigned long long const left = seen < A.n_items ? A.n_items - seen : 0ull;
+        unsigned long long const left = seen < A.queue_items ? A.queue_items - seen : 0ull;
         unsigned long long const want = left / ((unsigned long long)kGuide * A.guide_waves) / kItemBatch * kItemBatch;
         size = (uint32_t)min(max(want, (unsigned long long)A.batch_min), (unsigned long long)A.batch_items);
       }
@@ -157,7 +159,7 @@ struct ItemPool
       refills += 1u;
       end = __builtin_amdgcn_readfirstlane(base);
       reserved_end = end + size;
-      exhausted = end >= A.n_items;
+      exhausted = end >= A.queue_items;
 #if defined(RT_PROFILE_REGIONS)
       if (exhausted)
         timeline_mark(3);
@@ -165,6 +167,7 @@ struct ItemPool
     }
     next = end;
     end = next + kItemBatch;
+    delta = queue_item(A, next) - next;
   }
 
   // The queue position handed to this lane, or RT_INVALID.
@@ -188,7 +191,7 @@ struct ItemPool
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (need && rank < avail)
       {
-        result = (next + rank < A.n_items) ? next + rank : RT_INVALID;
+        result = (next + rank < A.queue_items) ? next + rank + delta : RT_INVALID;
         need = false;
       }
       next += wanted < avail ? wanted : avail;
@@ -320,9 +323,9 @@ struct WaveEnv
         pool.refill(A);
         ColumnEntry e;
         e.pixel = RT_INVALID;
-        if (pool.next + lane < A.n_items)
+        if (pool.next + lane < A.queue_items)
         {
-          e = prepare_column(A, cam, pool.next + lane);
+          e = prepare_column(A, cam, pool.next + lane + pool.delta);
           info.filter_tests += 1u;
         }
         batch[lane] = e;
@@ -336,7 +339,7 @@ struct WaveEnv
         ColumnEntry const e = batch[pool.next + rank - (pool.end - kItemBatch)];
         if (e.pixel != RT_INVALID)
         {
-          info.pos = pool.next + rank;
+          info.pos = pool.next + rank + pool.delta;
           info.prepared = true;
           info.sdx = e.sdx;
           info.dyp = e.dyp;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(256) void fold_kernel(float * __restrict__ partial,
 // adds its outer loop, ray_tracing/frame.cpp:56).  partial: the column sums (interleaved RGB), s_row consecutive
 // entries per pixel; planes: 3 planes of n floats.  One lane per pixel.
 __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ partial, float * __restrict__ planes,
-                                                     uint32_t n, uint32_t s_row)
+                                                     uint32_t n, uint32_t s_row, uint32_t own_stride, uint32_t own_first)
 {
   uint32_t const stride = gridDim.x * blockDim.x;
   bool const wide = (s_row % 4u) == 0u;
@@ -624,7 +627,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ 
   {
     const float * c = partial + 3u * (size_t)p * s_row;
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    if (wide)
+    // (own_stride > 1: slices by runs of kRunPixels pixels; the pixels of other slices' runs have no sums here)
+    if (own_stride > 1u && (p / kRunPixels) % own_stride != own_first)
+      ;
+    else if (wide)
     {
       // a multiple of four columns: 48-byte groups, 16-byte aligned
       const float4 * v = reinterpret_cast<const float4 *>(c);
@@ -658,8 +664,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float * __restrict__ 
 // sums, bit for bit.
 template <uint32_t kS, uint32_t kPixels>
 __global__ __launch_bounds__(256) void colsum_lds_kernel(const float * __restrict__ partial, float * __restrict__ planes,
-                                                         uint32_t n)
+                                                         uint32_t n, uint32_t own_stride, uint32_t own_first)
 {
+  static_assert(kRunPixels % kPixels == 0u, "a group of pixels lies in one run");
   constexpr uint32_t kRow = 3u * kS;        // floats per pixel
   constexpr uint32_t kPad = kRow | 1u;      // LDS row length: odd
   static_assert((kPixels * kRow) % 4u == 0u, "a wave's run starts on a 16-byte boundary");
@@ -671,6 +678,18 @@ __global__ __launch_bounds__(256) void colsum_lds_kernel(const float * __restric
   {
     uint32_t const p0 = group * kPixels;
     uint32_t const count = min(kPixels, n - p0);
+    if (own_stride > 1u && (p0 / kRunPixels) % own_stride != own_first)
+    {
+      // another slice's run: zero sums
+      if (lane < count)
+      {
+        uint32_t const p = p0 + lane;
+        planes[p] = 0.0f;
+        planes[n + p] = 0.0f;
+        planes[2u * (size_t)n + p] = 0.0f;
+      }
+      continue;
+    }
     uint32_t const total = count * kRow;
     const float * const src = partial + (size_t)p0 * kRow;
     for (uint32_t g = 4u * lane; g < total; g += 256u)
@@ -880,6 +899,8 @@ bool cones_disabled() { return std::getenv("RT_HIP_NO_CONES") != nullptr; }
 
 // RT_HIP_NO_SHARING (any value) switches sample sharing at the end of the queue off, for comparisons.
 bool share_disabled() { return std::getenv("RT_HIP_NO_SHARING") != nullptr; }
+// Slices by runs of pixels (RT_HIP_FLAG_PIXEL_RUNS) instead of by samples.
+bool pixel_runs(const rt_hip_trace_params * p) { return (p->flags & RT_HIP_FLAG_PIXEL_RUNS) != 0u && p->slice_count > 1u; }
 
 bool uses_grid(const rt_hip_scene * sc, uint32_t flags) { return (flags & RT_HIP_FLAG_GRID) != 0u && sc->has_grid; }
 
@@ -1015,11 +1036,9 @@ int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, bool library_math
 // against every sphere, so a sample against 10 000 spheres takes a hundred and fifty times what one against the
 // 64 spheres these sizes were tuned on does, and a reservation sized in samples alone would keep a wave busy for
 // tens of milliseconds after the queue has run dry.)
-uint32_t batch_items(const rt_hip_trace_params * p, int compute_units, unsigned long long cost)
+// `items`: positions in the launch's queue; `per_column`: samples the launch traces of a column.
+uint32_t batch_items(unsigned long long items, unsigned long long per_column, int compute_units, unsigned long long cost)
 {
-  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
-  unsigned long long const items = (unsigned long long)p->width * p->height * p->samples_in_row;
-  unsigned long long const per_column = std::max<unsigned long long>(1u, p->samples_in_row / g);  // of this slice
   unsigned long long const waves = (unsigned long long)std::max(compute_units, 1) * 4u * kWavesPerSimd;
   unsigned long long k = (1024u / cost + kItemBatch * per_column - 1u) / (kItemBatch * per_column);
   // ... and never fewer than four windows where a sample costs little: every reservation is an atomic on one word
@@ -1034,10 +1053,8 @@ uint32_t batch_items(const rt_hip_trace_params * p, int compute_units, unsigned 
 
 // Smallest reservation near the end of the queue: about 256 samples' worth (the counter word stays well below
 // its limit even if every reservation were that small), at least one window (two where a sample costs little).
-uint32_t batch_min(const rt_hip_trace_params * p, uint32_t batch, unsigned long long cost)
+uint32_t batch_min(unsigned long long per_column, uint32_t batch, unsigned long long cost)
 {
-  unsigned long long const g = p->slice_count ? p->slice_count : 1u;
-  unsigned long long const per_column = std::max<unsigned long long>(1u, p->samples_in_row / g);
   unsigned long long k = std::max<unsigned long long>(1u, (256u / cost + kItemBatch * per_column - 1u) / (kItemBatch * per_column));
   if (cost == 1u)
     k = std::max<unsigned long long>(k, 2u);  // single windows cost more in atomics than they gain in balance
@@ -1128,16 +1145,35 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.cone_inv_cos = scene->cone0.cos_m > 0.0f ? 1.0f / scene->cone0.cos_m : 1.0f;
   a.partial = d_partial;
   a.n_items = p->width * p->height * p->samples_in_row;
+  a.queue_items = a.n_items;
+  if (pixel_runs(p))
+  {
+    // this slice's runs of kRunPixels pixels, every sample of them (include/rt_hip.h RT_HIP_FLAG_PIXEL_RUNS)
+    a.run_items = kRunPixels * p->samples_in_row;
+    a.run_stride = a.slice_count;
+    a.run_first = a.slice_index;
+    unsigned long long const runs = ((unsigned long long)a.n_items + a.run_items - 1u) / a.run_items;
+    unsigned long long const own = runs > a.run_first ? (runs - a.run_first + a.run_stride - 1u) / a.run_stride : 0u;
+    unsigned long long positions = own * a.run_items;
+    if (own != 0u && (runs - 1u) % a.run_stride == a.run_first)
+      positions -= runs * a.run_items - a.n_items;  // the frame's last run is this slice's, and short
+    a.queue_items = (uint32_t)positions;
+    a.slice_count = 1u;
+    a.slice_index = 0u;
+    a.s_row_mod = 0u;
+  }
+  unsigned long long const per_column = std::max<uint32_t>(1u, a.s_row / a.slice_count);  // samples of a column traced here
   a.stats = want_stats ? d_stats : nullptr;
   a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
   a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
   unsigned long long const cost = uses_grid(scene, p->flags) ? 1u : std::max<unsigned long long>(1u, scene->n_spheres / 64u);
-  a.batch_items = batch_items(p, g_lib.compute_units, cost);
+  a.batch_items = batch_items(a.queue_items, per_column, g_lib.compute_units, cost);
   if (const char * v = std::getenv("RT_HIP_BATCH_ITEMS"))  // experiments: reservation size in items (a multiple of 64)
     a.batch_items = std::max<uint32_t>(kItemBatch, (uint32_t)std::strtoul(v, nullptr, 10) / kItemBatch * kItemBatch);
-  // A frame that overlaps with the next one on another stream keeps full reservations to the end: the next
-  // frame's waves fill what its end leaves idle, and the smaller reservations would only cost throughput.
-  a.batch_min = (p->flags & RT_HIP_FLAG_PIPELINED) ? a.batch_items : batch_min(p, a.batch_items, cost);
+  // (RT_HIP_FLAG_PIPELINED once kept the reservations of a frame in a stream of frames large to the end; since
+  // reservations are four windows, shrinking them at the end is better there too: 17.64 -> 17.50 ms per 1080p 16x16
+  // frame, 2.93 -> 2.62 ms per 1/8 of one, 337 -> 329 ms per 3840x2160 32x32 frame.  The flag is accepted and ignored.)
+  a.batch_min = batch_min(per_column, a.batch_items, cost);
   if (const char * v = std::getenv("RT_HIP_BATCH_MIN"))  // experiments: smallest reservation in items
     a.batch_min = std::min(a.batch_items, std::max<uint32_t>(kItemBatch, (uint32_t)std::strtoul(v, nullptr, 10) / kItemBatch * kItemBatch));
 
@@ -1157,9 +1193,9 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.column_masks = (uses_column_masks(scene) && !uses_grid(scene, p->flags)) ? 1u : 0u;
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
   bool const leave_room = (p->flags & RT_HIP_FLAG_LEAVE_ROOM) != 0u ||
-                          (d_cancel != nullptr && (unsigned long long)a.n_items * a.s_row / a.slice_count >= kSnapshotRoomSamples);
-  int const blocks = persistent_blocks(scene, p->flags, library_math, a.n_items,
-                                       (unsigned long long)a.n_items * a.s_row / a.slice_count, leave_room);
+                          (d_cancel != nullptr && (unsigned long long)a.queue_items * per_column >= kSnapshotRoomSamples);
+  int const blocks = persistent_blocks(scene, p->flags, library_math, std::max<uint32_t>(a.queue_items, 1u),
+                                       (unsigned long long)a.queue_items * per_column, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   size_t const lds = lds_bytes(scene, p->flags);
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
@@ -1205,11 +1241,13 @@ int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_
                   bool beside_trace = false)
 {
   uint32_t const n = p->width * p->height;
+  uint32_t const own_stride = pixel_runs(p) ? p->slice_count : 1u;
+  uint32_t const own_first = pixel_runs(p) ? p->slice_index % p->slice_count : 0u;
   // the sample counts of the reference's demos and of the benchmark go through LDS (whole-line loads)
   auto through_lds = [&](auto kernel, uint32_t pixels_per_wave) {
     uint32_t const groups = (n + pixels_per_wave - 1u) / pixels_per_wave;
     int const blocks = (int)std::min<uint32_t>((groups + 3u) / 4u, 256u * 3u);
-    hipLaunchKernelGGL(kernel, dim3(std::max(blocks, 1)), dim3(256), 0, stream, d_partial, d_planes, n);
+    hipLaunchKernelGGL(kernel, dim3(std::max(blocks, 1)), dim3(256), 0, stream, d_partial, d_planes, n, own_stride, own_first);
   };
   switch ((beside_trace || std::getenv("RT_HIP_PLAIN_COLSUM")) ? 0u : p->samples_in_row)
   {
@@ -1222,7 +1260,8 @@ int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_
   default:
   {
     int const blocks = (int)std::min<uint32_t>((n + 255u) / 256u, 256u * 8u);
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, d_planes, n, p->samples_in_row, own_stride,
+                       own_first);
   }
   }
   RT_CHECK(hipGetLastError());

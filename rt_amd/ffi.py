@@ -12,6 +12,7 @@ FLAG_DETERMINISTIC = 1
 FLAG_GRID = 2
 FLAG_PIPELINED = 4
 FLAG_LEAVE_ROOM = 8
+FLAG_PIXEL_RUNS = 16
 
 RT_HIP_OK = 0
 RT_HIP_ERR_NOT_READY = 3

@@ -15,12 +15,24 @@ def owner_of(pixel, sx, sy, samples_in_row, slice_count):
     return ((pixel * samples_in_row + sx) * samples_in_row + sy) % max(slice_count, 1)
 
 
-def slice_params(make_params, rank, world_size):
-    """Trace parameters of `rank`: the caller's parameters restricted to its slice."""
+def slice_params(make_params, rank, world_size, pixel_runs=False):
+    """Trace parameters of `rank`: the caller's parameters restricted to its slice.  pixel_runs: the slices divide
+    the frame by runs of 64 pixels (RT_HIP_FLAG_PIXEL_RUNS: a rank traces every sample of its pixels, and the
+    reduced frame equals the one-GPU frame bit for bit) instead of by samples."""
     p = make_params()
     p.slice_index = rank % max(world_size, 1)
     p.slice_count = max(world_size, 1)
+    if pixel_runs and world_size > 1:
+        p.flags |= FLAG_PIXEL_RUNS
     return p
+
+
+FLAG_PIXEL_RUNS = 16  # include/rt_hip.h RT_HIP_FLAG_PIXEL_RUNS
+
+
+def run_owner(pixel, slice_count, run_pixels=64):
+    """Slice that owns `pixel` when the frame is divided by runs of pixels."""
+    return (pixel // run_pixels) % max(slice_count, 1)
 
 
 def reduce_to_root(dist, tensor, world_size, root=0):

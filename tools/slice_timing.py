@@ -20,17 +20,21 @@ r = ffi.HipRenderer(0)
 demo = int(sys.argv[5]) if len(sys.argv) >= 6 else 1
 scene = ffi.Scene.demo(demo, 1, int(sys.argv[6]) if len(sys.argv) >= 7 else 10000)
 w, h, s = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1920, 1080, 16)
-planes = [torch.empty(3 * w * h, dtype=torch.float32, device="cuda") for _ in range(2)]
-stats = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(2)]
+planes = [torch.empty(3 * w * h, dtype=torch.float32, device="cuda") for _ in range(4)]
+stats = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(4)]
 # one stream, then two streams taking turns (different priorities, so that HIP gives them hardware queues of
 # their own): the second number is the period of a stream of frames whose ends and starts overlap
-streams = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)]
+LANES = int(os.environ.get("RT_LANES", "2"))  # frames in flight in the second measurement
+print("stream priority range", torch.cuda.Stream.priority_range())
+streams = [torch.cuda.Stream(priority=-(i % 3)) for i in range(max(LANES, 2))]
+RUNS = os.environ.get("RT_SLICE_BY", "runs") != "samples"  # slices by runs of pixels (bench.py's default) or by samples
+print("slices by %s" % ("runs of 64 pixels" if RUNS else "samples"))
 base = None
 for g in ([int(v) for v in sys.argv[4].split(",")] if len(sys.argv) >= 5 else (1, 2, 4, 8)):
     ms = []
-    for lanes in (1, 2):
-        flags = ffi.FLAG_PIPELINED if lanes == 2 else 0
-        p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), 0, g)
+    for lanes in (1, LANES):
+        flags = ffi.FLAG_PIPELINED if lanes >= 2 else 0
+        p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), 0, g, pixel_runs=RUNS)
         for k in range(4 if demo != 3 else 1):
             r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
         torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time of one configuration (HIP events around the trace kernel, launched alone):
-  python tools/time_kernel.py DEMO WIDTH HEIGHT SAMPLES [SPHERES] [LAUNCHES] [grid] [slices=N]
+  python tools/time_kernel.py DEMO WIDTH HEIGHT SAMPLES [SPHERES] [LAUNCHES] [grid] [slices=N] [runs]
 RT_AMD_LIB_DIR selects another build of the libraries."""
 import os
 import sys
@@ -15,6 +15,8 @@ flags = ffi.FLAG_GRID if "grid" in sys.argv[7:] else 0
 slices = max([int(a.split("=")[1]) for a in sys.argv[7:] if a.startswith("slices=")] + [1])
 r = ffi.HipRenderer(0)
 scene = ffi.Scene.demo(demo, 1, spheres)
+if "runs" in sys.argv[7:]:  # slices by runs of pixels instead of by samples
+    flags |= ffi.FLAG_PIXEL_RUNS
 p = ffi.params(w, h, s, seed=1, flags=flags, slice_index=slices - 1, slice_count=slices)
 r.time_trace_kernel(scene, p, 1)
 ms, st = r.time_trace_kernel(scene, p, launches)
