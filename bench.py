@@ -2,7 +2,8 @@
 """Headline benchmark: pretty_spheres, 1920x1080, 16x16 supersampling, traced on N MI355X GPUs.
 
 A step is one whole frame with the scene already resident in HBM: every rank traces its slice of the
-sample space (rt_hip_trace_device), the planar sums are reduced to rank 0 over RCCL, and rank 0 runs the
+frame (rt_hip_trace_device; runs of 64 pixels dealt out to the ranks in turn, --sample-slices for every rank's share
+of every pixel's samples), the planar sums are reduced to rank 0 over RCCL, and rank 0 runs the
 resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.  Two frames
 are in flight, on two streams with their own planes: while the planes of frame k are being reduced, every rank
 already traces frame k + 1, whose first waves also take over the compute units that the last waves of frame k

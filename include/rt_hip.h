@@ -18,7 +18,8 @@
  *     reference's loops visit them, are dealt out to the slices in turn (sample number % slice_count;
  *     slice_count < 65536), so every slice takes every slice_count-th sample of each column.  The sums
  *     of all slices add up to the whole frame, which is how one frame is sharded over several GPUs
- *     (one process per GPU; the caller reduces the planes).
+ *     (one process per GPU; the caller reduces the planes).  RT_HIP_FLAG_PIXEL_RUNS deals out runs of
+ *     pixels instead.
  *
  * Threads
  *   - The library serves one device per process (the one rt_hip_init selected).  rt_hip_init for another device

@@ -2,7 +2,8 @@
 
 The samples of a frame, numbered (pixel, sx, sy) in the order Frame::ForEachRayImpl visits them
 (ray_tracing/frame.cpp:44-66), are dealt out to the slices in turn: sample (p * S + sx) * S + sy belongs to slice
-number (that index) % slice_count.  Every rank traces its slice into planar sums; one sum-reduce to rank 0
+number (that index) % slice_count -- or, with pixel_runs, the pixels are: run number (p // 64) belongs to slice
+(that number) % slice_count, with all of its samples.  Every rank traces its slice into planar sums; one sum-reduce to rank 0
 (RCCL over xGMI when the tensors live on GPUs, gloo on CPUs) rebuilds the frame's sums, which rank 0 then
 normalises.  The reference has no counterpart: its CUDA backend is single-GPU (rt_cuda/rt_cuda.cu:80).
 """
