@@ -1,7 +1,10 @@
 """What one rank of G does per frame: the time of rt_hip_trace_device (trace + accumulate pass) on slice 0 of G
 of the headline frame, against 1/G of the whole frame.  Leaves out the RCCL reduce, which needs the other GPUs.
 
-python tools/slice_timing.py [width height samples_in_row [slice counts [demo [spheres]]]]       (RT_LIB_DIR=dir picks another build of the libraries)
+python tools/slice_timing.py [width height samples_in_row [slice counts [demo [spheres]]]]
+Environment: RT_SLICE_BY=samples for slices by samples (default: by runs of 64 pixels, as bench.py shards),
+RT_LANES=n for n frames in flight in the second measurement (default 2), RT_AMD_LIB_DIR=dir for another build of
+the libraries.
 """
 import os
 import sys
@@ -12,9 +15,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from rt_amd import ffi, sharding  # noqa: E402
-
-if os.environ.get("RT_LIB_DIR"):
-    ffi._LIB_DIR = os.path.abspath(os.environ["RT_LIB_DIR"])
 
 r = ffi.HipRenderer(0)
 demo = int(sys.argv[5]) if len(sys.argv) >= 6 else 1
