@@ -1,5 +1,12 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+"""Slices by runs of pixels (RT_HIP_FLAG_PIXEL_RUNS) against the whole frame, bit for bit, over a handful of frame
+shapes, scenes and slice counts (the same property tests/test_gpu_pixel_runs.py checks, with the 1080p frame).
+
+python tools/runs_check.py
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rt_amd import ffi, sharding
 r = ffi.HipRenderer(0)
