@@ -1149,18 +1149,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   if (pixel_runs(p))
   {
     // this slice's runs of kRunPixels pixels, every sample of them (include/rt_hip.h RT_HIP_FLAG_PIXEL_RUNS)
-    a.run_items = kRunPixels * p->samples_in_row;
-    a.run_stride = a.slice_count;
-    a.run_first = a.slice_index;
-    unsigned long long const runs = ((unsigned long long)a.n_items + a.run_items - 1u) / a.run_items;
-    unsigned long long const own = runs > a.run_first ? (runs - a.run_first + a.run_stride - 1u) / a.run_stride : 0u;
-    unsigned long long positions = own * a.run_items;
-    if (own != 0u && (runs - 1u) % a.run_stride == a.run_first)
-      positions -= runs * a.run_items - a.n_items;  // the frame's last run is this slice's, and short
-    a.queue_items = (uint32_t)positions;
-    a.slice_count = 1u;
-    a.slice_index = 0u;
-    a.s_row_mod = 0u;
+    set_pixel_runs(a, kRunPixels);
   }
   unsigned long long const per_column = std::max<uint32_t>(1u, a.s_row / a.slice_count);  // samples of a column traced here
   a.stats = want_stats ? d_stats : nullptr;

@@ -42,6 +42,26 @@ inline void prepare_frame(const rt_hip_camera & cam, const rt_hip_trace_params &
   a.s_row_mod = p.samples_in_row % a.slice_count;
 }
 
+// Slices by runs of pixels: the frame's items are dealt out in runs of run_pixels pixels (every column of them) to the
+// slices a.slice_index of a.slice_count in turn.  Sets up this slice's queue (TraceArgs::run_items and
+// queue_item, rt_core.h) and switches the slicing by samples off: the slice traces every sample of its columns.
+// run_pixels * s_row must be a multiple of the queue's window.
+inline void set_pixel_runs(TraceArgs & a, uint32_t run_pixels)
+{
+  a.run_items = run_pixels * a.s_row;
+  a.run_stride = a.slice_count;
+  a.run_first = a.slice_index;
+  unsigned long long const runs = ((unsigned long long)a.n_items + a.run_items - 1u) / a.run_items;
+  unsigned long long const own = runs > a.run_first ? (runs - a.run_first + a.run_stride - 1u) / a.run_stride : 0u;
+  unsigned long long positions = own * a.run_items;
+  if (own != 0u && (runs - 1u) % a.run_stride == a.run_first)
+    positions -= runs * a.run_items - a.n_items;  // the frame's last run is this slice's, and short
+  a.queue_items = (uint32_t)positions;
+  a.slice_count = 1u;
+  a.slice_index = 0u;
+  a.s_row_mod = 0u;
+}
+
 // Bound on |D_s - D_c| between the direction through the middle of a sub-sample column and the direction of
 // any of its samples: the unnormalised directions differ by at most |up| * cell_y / 2 and are at least
 // znear * |dir| long; the slack covers the approximate normalisation of D_c and float rounding.

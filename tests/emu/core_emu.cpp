@@ -118,6 +118,25 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
 static unsigned long long g_last_split_count = 0;
 extern "C" unsigned long long emu_last_split_count() { return g_last_split_count; }
 
+// The queue of slice `index` of `count` when a frame of n_pixels x s_row items is divided by runs of run_pixels
+// pixels (rt_prep.h set_pixel_runs, rt_core.h queue_item): writes the item of every queue position to `items`
+// (room for n_pixels * s_row entries) and returns the number of positions.
+extern "C" uint32_t emu_pixel_run_queue(uint32_t n_pixels, uint32_t s_row, uint32_t run_pixels, uint32_t index, uint32_t count,
+                                        uint32_t * items)
+{
+  rtc::TraceArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.s_row = s_row;
+  a.n_items = n_pixels * s_row;
+  a.queue_items = a.n_items;
+  a.slice_count = count ? count : 1u;
+  a.slice_index = index % a.slice_count;
+  rtc::set_pixel_runs(a, run_pixels);
+  for (uint32_t k = 0; k < a.queue_items; ++k)
+    items[k] = rtc::queue_item(a, k);
+  return a.queue_items;
+}
+
 extern "C" int emu_forward_ok(const rt_hip_material * mats, uint32_t m)
 {
   return rtc::forward_accumulation_ok(mats, m) ? 1 : 0;

@@ -28,3 +28,27 @@ def test_header_declares_the_flag():
 
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rt_hip.h")).read()
     assert "#define RT_HIP_FLAG_PIXEL_RUNS 16u" in text
+
+
+def test_every_item_is_in_exactly_one_slice_queue():
+    """The kernels' own bookkeeping (rt_prep.h set_pixel_runs, rt_core.h queue_item, compiled for the host): over the
+    slices, the queues hold every item of the frame once, each in the slice that owns its run, in increasing order."""
+    import ctypes as C
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "tests", "emu", "libcore_emu.so"))
+    lib.emu_pixel_run_queue.restype = C.c_uint32
+    lib.emu_pixel_run_queue.argtypes = [C.c_uint32] * 5 + [C.c_void_p]
+    for pixels, s, slices in [(1, 1, 2), (63, 2, 2), (64, 16, 2), (65, 3, 3), (1000, 10, 8), (128, 4, 5), (4321, 16, 7),
+                              (20736, 16, 8)]:
+        seen = np.zeros(pixels * s, dtype=np.int32)
+        for rank in range(slices):
+            items = np.zeros(pixels * s, dtype=np.uint32)
+            n = lib.emu_pixel_run_queue(pixels, s, 64, rank, slices, items.ctypes.data)
+            mine = items[:n].astype(np.int64)
+            assert np.all(np.diff(mine) > 0)
+            assert np.all(mine < pixels * s)
+            assert np.all(((mine // s) // 64) % slices == rank)
+            seen[mine] += 1
+        assert np.all(seen == 1), (pixels, s, slices)
