@@ -1,7 +1,8 @@
 """Random small frames through the HIP backend against the oracle: sizes, samples per row, slices, flags and
 scenes drawn at random.  Deterministic frames must match the oracle per pixel (1e-4 relative) with equal query
 counters; stochastic frames must not change a bit when sample sharing is switched off, RT_HIP_FLAG_PIPELINED is set
-or the shadow cones are switched off (scenes with several lights of any length included).
+or the shadow cones are switched off (scenes with several lights of any length included), and the images of a
+frame's slices by runs of pixels must add up to the frame's image bit for bit.
 
 python tools/fuzz_parity.py [SECONDS] [SEED]
 """
@@ -121,6 +122,18 @@ while time.time() < t_end:
     d, sd = r.render(plain[si], sto)  # the same scene without shadow cones
     stable = np.array_equal(a, b) and np.array_equal(a, c) and sa.ray_queries == sb.ray_queries == sc.ray_queries
     stable = stable and np.array_equal(a, d) and sa.hit_queries == sd.hit_queries
+    # slices by runs of pixels: the images of g2 slices add up to the whole frame's image bit for bit
+    if cases % 4 == 0:
+        g2 = int(rng.choice([2, 3, 5]))
+        whole, sw = r.render(scene, ffi.params(w, h, s, flags=grid, seed=seed, max_depth=depth))
+        total = np.zeros_like(whole)
+        queries = 0
+        for k in range(g2):
+            part, sp = r.render(scene, ffi.params(w, h, s, flags=grid | ffi.FLAG_PIXEL_RUNS, seed=seed, max_depth=depth,
+                                                  slice_index=k, slice_count=g2))
+            total += part
+            queries += sp.ray_queries
+        stable = stable and np.array_equal(total.view(np.uint32), whole.view(np.uint32)) and queries == sw.ray_queries
     cases += 1
     if cases % 50 == 0:
         print("%d cases so far, worst deterministic error %.3g" % (cases, worst), flush=True)
