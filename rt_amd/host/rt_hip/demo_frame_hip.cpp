@@ -75,7 +75,7 @@ void DemoFrameHIP::TraceAllRays()
   params.width = m_width;
   params.height = m_height;
   params.samples_in_row = m_samplesInRowCount;
-  params.flags = m_deterministic ? RT_HIP_FLAG_DETERMINISTIC : 0u;
+  params.flags = (m_deterministic ? RT_HIP_FLAG_DETERMINISTIC : 0u) | (m_pixelRuns ? RT_HIP_FLAG_PIXEL_RUNS : 0u);
   params.seed = m_seed;
   params.max_depth = m_maxDepth;
   params.slice_index = m_sliceIndex;

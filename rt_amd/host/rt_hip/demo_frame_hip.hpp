@@ -40,7 +40,9 @@ public:
   void SetSeed(uint32_t seed) { m_seed = seed; }
   void SetDeterministic(bool on) { m_deterministic = on; }
   void SetMaxDepth(uint32_t depth) { m_maxDepth = depth; }
-  void SetSampleSlice(uint32_t index, uint32_t count) { m_sliceIndex = index; m_sliceCount = count; }
+  void SetSampleSlice(uint32_t index, uint32_t count) { m_sliceIndex = index; m_sliceCount = count; m_pixelRuns = false; }
+  // The same slice cut by runs of 64 pixels (RT_HIP_FLAG_PIXEL_RUNS): every sample of every count-th run.
+  void SetPixelRunSlice(uint32_t index, uint32_t count) { m_sliceIndex = index; m_sliceCount = count; m_pixelRuns = true; }
 
   bool Failed() const { return m_failed; }
   std::string const & LastError() const { return m_error; }
@@ -58,6 +60,7 @@ private:
   uint32_t m_maxDepth = 0;
   uint32_t m_sliceIndex = 0;
   uint32_t m_sliceCount = 1;
+  bool m_pixelRuns = false;
 
   SceneFlattener m_flat;  // must not change while a frame is in flight
   bool m_sceneDirty = true;
