@@ -15,10 +15,12 @@ def test_static_scratch_entry_point_matches_the_allocating_one(hip, ffi, scenes)
     import torch
 
     stream = torch.cuda.current_stream().cuda_stream
-    # two calls in a row, the second with a smaller frame (and another scene, seed and a slice)
+    # calls in a row, each with a smaller frame than the one before (and another scene, seed and a slice; the last
+    # one a slice by runs of pixels)
     cases = [
         (scenes(1), ffi.params(1024, 768, 2, seed=3)),
         (scenes(2), ffi.params(320, 200, 3, seed=9, slice_index=1, slice_count=2)),
+        (scenes(1), ffi.params(200, 120, 4, seed=4, slice_index=2, slice_count=3, flags=ffi.FLAG_PIXEL_RUNS)),
     ]
     expected = []
     for scene, p in cases:
