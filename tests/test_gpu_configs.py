@@ -45,6 +45,59 @@ def test_headline_frame_rows_against_the_cpu_path(hip, oracle, ffi, scenes):
         assert abs(float(ref.mean()) - float(band.mean())) < 1e-5
 
 
+# ---- pretty_spheres 1024x768, 2x2: the reference's default window (main.cpp:58-62), the whole frame ----
+
+def test_default_window_whole_frame_against_the_cpu_path(hip, oracle, ffi, scenes):
+    scene = scenes(1)
+    w, h, s = 1024, 768, 2
+    p = ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC)
+    ref, rs = oracle.render(scene, p)
+    out, st = hip.render(scene, p)
+    err = rel_err(ref, out)
+    assert err.max() < 1e-4, "max relative error %.3g" % err.max()
+    assert query_counters(st) == (rs.samples, rs.ray_queries, rs.hit_queries, rs.shaded_bounces)
+    p = ffi.params(w, h, s, seed=1)
+    ref, rs = oracle.render(scene, p)
+    out, st = hip.render(scene, p)
+    assert st.samples == w * h * s * s == rs.samples
+    assert np.abs(ref - out).mean() < 5e-6
+    assert (rel_err(ref, out).max(axis=2) > 1e-3).mean() < 1e-3
+    assert abs(int(st.ray_queries) - int(rs.ray_queries)) < 1e-4 * rs.ray_queries
+    again, st2 = hip.render(scene, p)
+    np.testing.assert_array_equal(out, again)
+    assert query_counters(st) == query_counters(st2)
+
+
+# ---- glass_spheres 1024x768, 10x10: the viewer's high-quality mode (app.cpp:92-99) ----
+
+def test_glass_hq_frame_rows_against_the_cpu_path(hip, oracle, ffi, scenes):
+    """Rows of the 1024x768 10x10 glass frame itself: the oracle renders two bands of rows of that frame (one through
+    the spheres, one across the ground in front of them), the GPU the whole frame."""
+    scene = scenes(2)
+    w, h, s = 1024, 768, 10
+    bands = [(300, 316), (520, 536)]
+    p = ffi.params(w, h, s, flags=ffi.FLAG_DETERMINISTIC)
+    out, st = hip.render(scene, p)
+    assert st.samples == w * h * s * s
+    for lo, hi in bands:
+        ref, _ = oracle.render_rows(scene, p, lo, hi)
+        err = rel_err(ref, out[lo:hi])
+        assert err.max() < 1e-4, "rows %d-%d: max relative error %.3g" % (lo, hi, err.max())
+    p = ffi.params(w, h, s, seed=1)
+    out, st = hip.render(scene, p)
+    assert st.samples == w * h * s * s
+    assert st.samples + 5 * st.shaded_bounces <= st.ray_queries <= st.samples + 6 * st.shaded_bounces
+    for lo, hi in bands:
+        ref, _ = oracle.render_rows(scene, p, lo, hi)
+        band = out[lo:hi]
+        assert np.abs(ref - band).mean() < 5e-6
+        assert (rel_err(ref, band).max(axis=2) > 1e-3).mean() < 1e-3
+        assert abs(float(ref.mean()) - float(band.mean())) < 1e-5
+    again, st2 = hip.render(scene, p)
+    np.testing.assert_array_equal(out, again)
+    assert query_counters(st) == query_counters(st2)
+
+
 # ---- glass_spheres 3840x2160, 32x32 ----
 
 def test_glass_32x32_small_frame_against_the_cpu_path(hip, oracle, ffi, scenes):
