@@ -363,6 +363,16 @@ struct TraceArgs
   // outputs
   float * partial;            // per column (item), the sum of the samples this slice owns: partial[3 * item + c]
   uint32_t n_items;           // width * height * s_row
+  // Pixel sums taken inside the kernel (optional, ring_slots = 0: off; s_row must divide the 64-item window, so
+  // that a window holds whole pixels).  A wave parks the column sums of the windows it works on in LDS and, when the
+  // last column of a window is done, adds each pixel's columns in increasing sx (the order of the outer loop of
+  // ray_tracing/frame.cpp:56) and writes the three sums to planes[c * n_pixels + pixel]: no column sum goes to
+  // memory and `partial` is unused.  ring_slots: windows a wave may have unfinished at a time.
+  float * planes;
+  uint32_t n_pixels;
+  uint32_t ring_slots;
+  uint32_t s_shift;           // log2(s_row) when ring_slots != 0
+  unsigned long long * ring_errors;  // raised by a wave that gave up waiting for a free slot (never, in a correct launch)
   // Slices: the samples of the frame, numbered item * s_row + sy, are dealt out to the slices in turn, so this
   // slice traces the samples sy = first_sample(item), + slice_count, ... of every column.  The work queue is
   // the items in order; position k is item k.
@@ -608,11 +618,29 @@ RT_FN void fold_split(float * partial, const float * shared, u4 rec, uint32_t s_
   store3(c, sum);
 }
 
+// A finished column (or shared sample) goes to memory: one 12-byte store; every entry is written by exactly one
+// lane.  The owner of a column some of whose samples were shared out leaves a record for the fold pass.
+template <class Env>
+RT_FN void store_column(const TraceArgs & A, const Lane & L, Env & env)
+{
+  bool const shared_sample = (L.slot & RT_SHARED_SLOT) != 0u;
+  // one base pointer and an offset, not a choice between two pointers (which the compiler turns into a load
+  // of the chosen pointer from the argument block, a memory round trip in every round that ends a column)
+  size_t const at = 3u * (size_t)(L.slot & ~RT_SHARED_SLOT) + (shared_sample ? A.shared_off : (size_t)0);
+  store3(A.partial + at, L.sum);
+  if (!shared_sample && L.sy_end < A.s_row)
+    env.record_split(L.slot, L.sy_end);
+}
+
 // What an environment hands out with a work item.  When `prepared`, the column's ray set-up and candidate
 // masks were computed ahead (prepare_column); otherwise the lane runs begin_item itself.
 struct ItemInfo
 {
-  uint32_t pos;           // queue position; RT_INVALID: the slice is used up
+  uint32_t pos;           // the item; RT_INVALID: the slice is used up, or (stalled) nothing can be handed out right now
+  uint32_t slot;          // what Lane::slot becomes: where the column's sum goes (the item, unless the environment
+                          // keeps the sums of its windows itself)
+  bool stalled;           // wave-uniform: the environment could not open the next window yet; lanes without an item
+                          // ask again in a later round
   bool prepared;
   float sdx, dyp;
   uint32_t cm0, cm1, pixel, sx, sy0;
@@ -971,6 +999,9 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //   any_wave(p)       true if p holds for any lane of the wave
 //   fetch_item(need, info)  hands a fresh work item to each lane that asks (info.pos == RT_INVALID when the
 //                     slice is used up), prepared or not (see ItemInfo)
+//   finish_columns(L, finishing)  called by the whole wave when some lane's column (or shared sample) is complete:
+//                     the sums of the lanes with `finishing` leave their lanes (store_column, or the environment's
+//                     own pixel sums, TraceArgs::ring_slots)
 //   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i);  material(m, k) and
 //                     light(l, k): record k of material m / light l;  jitter_table()
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
@@ -1356,20 +1387,15 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
     for (;;)
     {
       cnt.rounds += 1;
-      bool need = L.alive && !L.has_hit && !L.shading;
-      // Column (or shared sample) complete: one 12-byte store; every entry is written by exactly one lane.
-      if (need && !L.need_item && L.sy >= L.sy_end)
-      {
-        bool const shared_sample = (L.slot & RT_SHARED_SLOT) != 0u;
-        // one base pointer and an offset, not a choice between two pointers (which the compiler turns into a load
-        // of the chosen pointer from the argument block, a memory round trip in every round that ends a column)
-        size_t const at = 3u * (size_t)(L.slot & ~RT_SHARED_SLOT) + (shared_sample ? A.shared_off : (size_t)0);
-        store3(A.partial + at, L.sum);
-        if (!shared_sample && L.sy_end < A.s_row)
-          env.record_split(L.slot, L.sy_end);
+      bool const need = L.alive && !L.has_hit && !L.shading;
+      // Column (or shared sample) complete: its sum leaves the lane.
+      bool const finishing = need && !L.need_item && L.sy >= L.sy_end;
+      if (env.any_wave(finishing))
+        env.finish_columns(L, finishing);
+      if (finishing)
         L.need_item = true;
-      }
       bool const ask = need && L.need_item;
+      bool waiting = false;  // the lane asked and the environment has to finish older windows first
       if (env.any(ask))
       {
         ItemInfo info;
@@ -1378,10 +1404,15 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         if (ask)
         {
           if (info.pos == RT_INVALID)
-            L.alive = false;
+          {
+            if (info.stalled)
+              waiting = true;
+            else
+              L.alive = false;
+          }
           else
           {
-            L.slot = info.pos;
+            L.slot = info.slot;
             if (info.prepared)
             {
               L.pixel = info.pixel;
@@ -1395,7 +1426,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
               L.sum = mk3(0.0f, 0.0f, 0.0f);
             }
             else
-              begin_item(A, L, L.slot);
+              begin_item(A, L, info.pos);
             L.need_item = false;
           }
         }
@@ -1444,7 +1475,8 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
         }
       }
       RT_REGION(cnt, 4);
-      bool const still = L.alive && !L.has_hit && !L.shading;
+      // (a lane that waits for a window is not looking for a hit: it can do nothing until other lanes' columns end)
+      bool const still = L.alive && !L.has_hit && !L.shading && !waiting;
       int const n_still = env.count(still);
       if (n_still == 0)
         break;

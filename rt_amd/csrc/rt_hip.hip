@@ -74,6 +74,7 @@ constexpr uint32_t kResidentSpheres = 256; // scenes up to this size live in LDS
 constexpr uint32_t kTileSpheres = 1024;   // larger scenes: 20 KB of LDS per staged tile of filter records and cone terms
 constexpr uint32_t kTileSpheresStack = 768;  // ... 15 KB where the path stacks (40 KB) share the block's 64 KB
 constexpr uint32_t kStatsWords = 9;
+constexpr uint32_t kStatsWordsAll = kStatsWords + 2;  // the counters, the queue word, TraceArgs::ring_errors
 
 // ---- rt_hip_trace_device_static: the one entry point that allocates nothing ----
 // Its scratch (counters, camera table, column sums, sample-sharing room) is this file-scope array instead of a
@@ -116,6 +117,191 @@ constexpr uint32_t kItemBatch = 64;
 constexpr uint32_t kRunPixels = 64;  // slices by pixels: pixels per run (its items: a multiple of kItemBatch)
 constexpr uint32_t kCancelPoll = 8;
 constexpr uint32_t kGuide = 16;
+
+// Pixel sums inside the trace kernel (TraceArgs::ring_slots).  Every wave keeps, in LDS, the column sums of the
+// windows it has handed out and not yet finished: `slots` windows of kItemBatch columns, each with a header
+//   [0] columns of the window that are items of the queue (0: the slot is free)   [1] columns done   [2] first pixel
+// A lane that finishes a column parks its sum in the window's slot and counts it; the lane that counts the last one
+// has the wave add each pixel's columns in increasing sx and write the pixel sums.  LDS operations of one wave are
+// carried out in program order, so a sum written in an earlier instruction (by any lane) is there when a later one
+// reads it; the wave-level fences only keep the compiler from moving the accesses.
+//
+// With sample sharing the sum of a column comes together in LDS too: `pending[l]` counts what is still missing of
+// the column lane l owns (the owner's own part and every sample handed to another lane), `meta[l]` holds where the
+// column belongs and the first sample that was handed out.  The colours of shared samples go through memory
+// (TraceArgs::shared) as they do for the fold pass; whoever brings pending[l] to zero adds them to the owner's part
+// in sample order -- the additions the owner would have made itself.
+constexpr uint32_t kRingHeaderWords = 4;
+constexpr uint32_t kRingMaxSlots = 8;
+constexpr uint32_t kRingMinSlots = 2;
+constexpr uint32_t kRingStallLimit = 1u << 16;  // rounds a wave may wait for a slot before it gives the frame up (a
+                                                // column of 64 samples of ten bounces ends within some 1500)
+__host__ __device__ constexpr size_t ring_bytes_per_wave(uint32_t slots)
+{
+  return slots == 0u ? 0u : sizeof(uint32_t) * (2u * 64u + kRingMaxSlots * kRingHeaderWords) + (size_t)slots * 3u * 64u * sizeof(float);
+}
+
+// LDS of one wave's ring: [pending 64][meta 64][headers kRingMaxSlots x kRingHeaderWords][sums slots x kItemBatch x 3].
+struct PixelRing
+{
+  uint32_t * words = nullptr;   // LDS: the wave's region (all offsets below are constants)
+  uint32_t slots = 0;
+  uint32_t head = 0;            // slot of the window being handed out
+  uint32_t stalls = 0;          // consecutive refusals of can_open
+
+  __device__ __forceinline__ uint32_t * pending() const { return words; }
+  __device__ __forceinline__ uint32_t * meta() const { return words + 64u; }
+  __device__ __forceinline__ uint32_t * hdr() const { return words + 128u; }
+  __device__ __forceinline__ float * sums() const { return reinterpret_cast<float *>(words + 128u + kRingMaxSlots * kRingHeaderWords); }
+
+  __device__ __forceinline__ void init(unsigned char * wave_lds, uint32_t n_slots)
+  {
+    slots = n_slots;
+    words = reinterpret_cast<uint32_t *>(wave_lds);
+    uint32_t const lane = __lane_id();
+    if (lane < kRingMaxSlots * kRingHeaderWords)
+      hdr()[lane] = 0u;
+    pending()[lane] = 0u;
+    meta()[lane] = 0u;
+    head = slots - 1u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ uint32_t next_head() const { return head + 1u == slots ? 0u : head + 1u; }
+  // May the next window be opened?  Not while the slot it would take still waits for columns.
+  __device__ __forceinline__ bool can_open() const
+  {
+    return __builtin_amdgcn_readfirstlane((int)hdr()[next_head() * kRingHeaderWords]) == 0;
+  }
+  // The window of `valid` columns whose first item is `first_item` takes the next slot.
+  __device__ __forceinline__ void opened(const TraceArgs & A, uint32_t valid, uint32_t first_item)
+  {
+    head = next_head();
+    if (__lane_id() == 0)
+    {
+      hdr()[head * kRingHeaderWords + 0u] = valid;
+      hdr()[head * kRingHeaderWords + 1u] = 0u;
+      hdr()[head * kRingHeaderWords + 2u] = first_item >> A.s_shift;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  // Completes the sum of the column lane `owner` of this wave owns: its own part, then the shared colours in
+  // increasing sy (rt_core.h fold_split does the same after the kernel).  Returns the column's place in the ring.
+  __device__ __forceinline__ uint32_t fold(const TraceArgs & A, uint32_t owner, uint32_t wave_first) const
+  {
+    uint32_t const m = meta()[owner];
+    uint32_t const wc = m & 0xFFFFu;
+    float * const s = sums() + 3u * wc;
+    f3 sum = mk3(s[0], s[1], s[2]);
+    size_t const base = (size_t)(wave_first + owner) * A.share_depth;
+    for (uint32_t sy = m >> 16; sy < A.s_row; sy += A.slice_count)
+    {
+      // written by other lanes of this wave: read past the vector cache, which may hold an older copy of the line
+      const float * const v = A.shared + 3u * (base + (A.s_row - 1u - sy));
+      float const x = __hip_atomic_load(v + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float const y = __hip_atomic_load(v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float const z = __hip_atomic_load(v + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sum = sum + mk3(x, y, z);
+    }
+    s[0] = sum.x;
+    s[1] = sum.y;
+    s[2] = sum.z;
+    return wc;
+  }
+
+  // Called by the whole wave; lanes with `finishing` have a complete column or shared sample in L.sum.
+  __device__ __forceinline__ void finish(const TraceArgs & A, const Lane & L, bool finishing)
+  {
+    uint32_t const lane = __lane_id();
+    uint32_t const wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
+    uint32_t done_col = RT_INVALID;  // place in the ring of a column this lane completed
+    if (finishing)
+    {
+      if ((L.slot & RT_SHARED_SLOT) == 0u)
+      {
+        uint32_t const wc = L.slot;
+        float * const s = sums() + 3u * wc;
+        s[0] = L.sum.x;
+        s[1] = L.sum.y;
+        s[2] = L.sum.z;
+        if (L.sy_end < A.s_row)
+        {
+          // samples of this column were handed to other lanes: this is the owner's part
+          meta()[lane] = wc | (L.sy_end << 16);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          if (atomicSub(&pending()[lane], 1u) == 1u)
+            done_col = fold(A, lane, wave_first);
+        }
+        else
+          done_col = wc;
+      }
+      else
+      {
+        uint32_t const owner = (L.slot >> 16) & 63u;
+        uint32_t const place = L.slot & 0xFFFFu;
+        if (place < A.share_depth)
+          store3(A.shared + 3u * ((size_t)(wave_first + owner) * A.share_depth + place), L.sum);
+        else
+          atomicAdd(A.ring_errors, 1ull);  // (never: the places of a region are share_depth)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the colour is in memory before it is counted
+        if (atomicSub(&pending()[owner], 1u) == 1u)
+          done_col = fold(A, owner, wave_first);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t full = RT_INVALID;  // a window this lane's column completed
+    if (done_col != RT_INVALID)
+    {
+      uint32_t const w = done_col >> 6;
+      uint32_t const before = atomicAdd(&hdr()[w * kRingHeaderWords + 1u], 1u);
+      if (before + 1u == hdr()[w * kRingHeaderWords + 0u])
+        full = w;
+    }
+    unsigned long long windows = __ballot(full != RT_INVALID);
+    while (windows != 0ull)
+    {
+      uint32_t const src = (uint32_t)__builtin_ctzll(windows);
+      windows &= windows - 1ull;
+      uint32_t const w = (uint32_t)__builtin_amdgcn_readlane((int)full, (int)src);
+      uint32_t const valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr()[w * kRingHeaderWords + 0u]);
+      uint32_t const first_pixel = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr()[w * kRingHeaderWords + 2u]);
+      if (lane < (valid >> A.s_shift))
+      {
+        // the accumulate pass of this pixel: 0 + column 0 + column 1 + ... as colsum_kernel adds them
+        const float * c = sums() + 3u * (w * 64u + (lane << A.s_shift));
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (uint32_t i = 0; i < A.s_row; ++i, c += 3)
+        {
+          r += c[0];
+          g += c[1];
+          b += c[2];
+        }
+        size_t const px = (size_t)first_pixel + lane;
+        if (px < A.n_pixels)
+        {
+          A.planes[px] = r;
+          A.planes[(size_t)A.n_pixels + px] = g;
+          A.planes[2u * (size_t)A.n_pixels + px] = b;
+        }
+        else
+          atomicAdd(A.ring_errors, 1ull);  // (never: a window's pixels are pixels of the frame)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0u)
+        hdr()[w * kRingHeaderWords + 0u] = 0u;  // the slot is free
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+};
 
 struct ItemPool
 {
@@ -170,10 +356,36 @@ struct ItemPool
     delta = queue_item(A, next) - next;
   }
 
-  // The queue position handed to this lane, or RT_INVALID.
-  __device__ __forceinline__ uint32_t fetch(const TraceArgs & A, bool need)
+  // The same with the wave's pixel sums in mind: false when the ring has no free slot for the window yet (older
+  // windows have unfinished columns; the lanes that asked ask again in a later round).  A wave that is refused
+  // kRingStallLimit times in a row -- which no frame does: a busy slot means a lane of this wave is still tracing
+  // one of its columns -- gives up: it reports the queue used up, so that the launch ends, and raises
+  // TraceArgs::ring_errors.
+  template <bool kFused>
+  __device__ __forceinline__ bool open(const TraceArgs & A, PixelRing & ring)
   {
-    uint32_t result = RT_INVALID;
+    if (kFused && !ring.can_open())
+    {
+      ring.stalls += 1u;
+      if (ring.stalls < kRingStallLimit)
+        return false;
+      if (__lane_id() == 0)
+        atomicAdd(A.ring_errors, 1ull);
+      exhausted = true;
+      next = end;
+      return true;
+    }
+    ring.stalls = 0u;
+    refill(A);
+    if (kFused && next < A.queue_items)
+      ring.opened(A, min(kItemBatch, A.queue_items - next), next + delta);
+    return true;
+  }
+
+  // Hands the next queue positions to the lanes that need one: info.pos (the item) and info.slot.
+  template <bool kFused>
+  __device__ __forceinline__ void fetch(const TraceArgs & A, PixelRing & ring, bool need, ItemInfo & info)
+  {
     uint32_t const lane = __lane_id();
     for (;;)
     {
@@ -184,19 +396,28 @@ struct ItemPool
       {
         if (exhausted)
           break;
-        refill(A);
+        if (!open<kFused>(A, ring))
+        {
+          info.stalled = true;
+          break;
+        }
+        if (next == end)
+          break;  // the wave gave up (see open)
       }
       uint32_t const avail = end - next;
       uint32_t const wanted = (uint32_t)__popcll(mask);
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (need && rank < avail)
       {
-        result = (next + rank < A.queue_items) ? next + rank + delta : RT_INVALID;
+        if (next + rank < A.queue_items)
+        {
+          info.pos = next + rank + delta;
+          info.slot = kFused ? ring.head * kItemBatch + (next + rank - (end - kItemBatch)) : info.pos;
+        }
         need = false;
       }
       next += wanted < avail ? wanted : avail;
     }
-    return result;
   }
 };
 
@@ -213,7 +434,8 @@ __device__ __forceinline__ float lane_value(float v, uint32_t lane)
 // to the lanes that still have samples to start, an even share each, taking samples from the end of the
 // owner's column.  Everything here is wave-wide and needs no memory traffic: the owner's ray set-up travels
 // through lane reads.  The region of a lane is its index in the launch, so no two owners share one.
-__device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L)
+template <bool kFused>
+__device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L, const PixelRing & ring)
 {
   if (A.share_depth == 0u)
     return;
@@ -241,11 +463,27 @@ __device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L)
     uint32_t const d_cm0 = lane_value(L.cm0, d), d_cm1 = lane_value(L.cm1, d);
     float const d_sdx = lane_value(L.sdx, d), d_dyp = lane_value(L.dyp, d);
     if (lane == d)
+    {
       L.sy_end = spare_sample_sy(A, d_sy, d_end, give - 1u);  // the owner keeps what lies below
+      // pixel sums in the kernel: what the column still waits for -- these samples and, counted with the first
+      // ones handed out, the owner's own part
+      if constexpr (kFused)
+        ring.pending()[d] += give + (d_end == A.s_row ? 1u : 0u);
+    }
     if (was_idle && my_rank >= taken && my_rank < taken + give)
-      take_shared_sample(A, L, (wave_first + d) * A.share_depth, d_pixel, d_sx, d_sdx, d_dyp, d_cm0, d_cm1,
-                         spare_sample_sy(A, d_sy, d_end, my_rank - taken));
+    {
+      uint32_t const sy = spare_sample_sy(A, d_sy, d_end, my_rank - taken);
+      take_shared_sample(A, L, (wave_first + d) * A.share_depth, d_pixel, d_sx, d_sdx, d_dyp, d_cm0, d_cm1, sy);
+      if constexpr (kFused)
+        L.slot = RT_SHARED_SLOT | (d << 16) | (A.s_row - 1u - sy);  // the owner's lane and the colour's place in its region
+    }
     taken += give;
+  }
+  if constexpr (kFused)
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -262,7 +500,7 @@ __device__ __forceinline__ void append_split(const TraceArgs & A, uint32_t slot,
 }
 
 // The whole scene is resident in LDS; waves never wait for each other.
-template <bool kLibMath>
+template <bool kLibMath, bool kFused>
 struct WaveEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
@@ -279,13 +517,21 @@ struct WaveEnv
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ColumnEntry * batch;   // LDS: this wave's kItemBatch prepared columns (column masks only)
   ItemPool pool;
+  PixelRing ring;
 
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
-  __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L, ring); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  __device__ __forceinline__ void finish_columns(Lane & L, bool finishing)
+  {
+    if constexpr (kFused)
+      ring.finish(A, L, finishing);
+    else if (finishing)
+      store_column(A, L, *this);
+  }
   __device__ __forceinline__ f4 sphere(int i) const { return exact[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return smat[i]; }
   __device__ __forceinline__ f4 material(uint32_t m, uint32_t k) const { return mats[RT_MAT_RECORDS * m + k]; }
@@ -303,11 +549,13 @@ struct WaveEnv
   __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
   {
     info.pos = RT_INVALID;
+    info.slot = RT_INVALID;
+    info.stalled = false;
     info.prepared = false;
     info.filter_tests = 0u;
     if (A.column_masks == 0u)
     {
-      info.pos = pool.fetch(A, need);
+      pool.template fetch<kFused>(A, ring, need, info);
       return;
     }
     uint32_t const lane = __lane_id();
@@ -320,7 +568,15 @@ struct WaveEnv
       {
         if (pool.exhausted)
           break;
-        pool.refill(A);
+        if (!pool.template open<kFused>(A, ring))
+        {
+          info.stalled = true;
+          break;
+        }
+        if (pool.next == pool.end)
+          break;  // the wave gave up (see ItemPool::open)
+        // (a window past the end of the queue gets invalid entries: lanes that ask later must not find the
+        // previous window's columns)
         ColumnEntry e;
         e.pixel = RT_INVALID;
         if (pool.next + lane < A.queue_items)
@@ -336,10 +592,12 @@ struct WaveEnv
       uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (need && rank < avail)
       {
-        ColumnEntry const e = batch[pool.next + rank - (pool.end - kItemBatch)];
+        uint32_t const column = pool.next + rank - (pool.end - kItemBatch);
+        ColumnEntry const e = batch[column];
         if (e.pixel != RT_INVALID)
         {
           info.pos = pool.next + rank + pool.delta;
+          info.slot = kFused ? ring.head * kItemBatch + column : info.pos;
           info.prepared = true;
           info.sdx = e.sdx;
           info.dyp = e.dyp;
@@ -358,7 +616,7 @@ struct WaveEnv
 
 // Larger scenes: the block re-stages the spheres (or the camera table) through one LDS tile inside every
 // pass, so all of its waves take the same trips and every loop decision is block-wide.
-template <bool kLibMath>
+template <bool kLibMath, bool kFused>
 struct BlockEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
@@ -373,18 +631,29 @@ struct BlockEnv
   const float * aux_src;  // where those come from: A.aux_cone for the one-light kernel, else A.aux_rw
   const float * jitter;   // LDS: RT_JITTER_FLOATS
   ItemPool pool;
+  PixelRing ring;
 
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
-  __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L, ring); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  __device__ __forceinline__ void finish_columns(Lane & L, bool finishing)
+  {
+    if constexpr (kFused)
+      ring.finish(A, L, finishing);
+    else if (finishing)
+      store_column(A, L, *this);
+  }
   __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
   {
+    info.pos = RT_INVALID;
+    info.slot = RT_INVALID;
+    info.stalled = false;
     info.prepared = false;
     info.filter_tests = 0u;
-    info.pos = pool.fetch(A, need);
+    pool.template fetch<kFused>(A, ring, need, info);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -413,7 +682,7 @@ struct BlockEnv
 
 // Grid walks: every ray finds its own spheres, read from global memory (the L2 holds the scene); waves never
 // wait for each other.  The tile functions are unused.
-template <bool kLibMath>
+template <bool kLibMath, bool kFused>
 struct GridEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
@@ -422,18 +691,29 @@ struct GridEnv
   const TraceArgs & A;
   const float * jitter;  // LDS: RT_JITTER_FLOATS
   ItemPool pool;
+  PixelRing ring;
 
   __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
-  __device__ __forceinline__ void share(Lane & L) const { share_samples(A, L); }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L, ring); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  __device__ __forceinline__ void finish_columns(Lane & L, bool finishing)
+  {
+    if constexpr (kFused)
+      ring.finish(A, L, finishing);
+    else if (finishing)
+      store_column(A, L, *this);
+  }
   __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
   {
+    info.pos = RT_INVALID;
+    info.slot = RT_INVALID;
+    info.stalled = false;
     info.prepared = false;
     info.filter_tests = 0u;
-    info.pos = pool.fetch(A, need);
+    pool.template fetch<kFused>(A, ring, need, info);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -495,7 +775,9 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
 // kLibMath: see rt_core.h Env::kLibraryMath (only the kernels for any number of lights come in that form).
-template <bool kTiled, bool kForward, bool kOneLight, bool kLibMath = false>
+// kFused: the kernel takes the pixel sums itself (PixelRing; only the kForward kernels with the short exact sequences
+// come in that form).
+template <bool kTiled, bool kForward, bool kOneLight, bool kLibMath = false, bool kFused = false>
 __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : (kTiled && kForward ? RT_TILED_WAVES : kWavesPerSimd)) void trace_kernel(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -513,8 +795,12 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   sph += RT_JITTER_FLOATS / 4u;
   if constexpr (kTiled)
   {
+    constexpr uint32_t kTile = kForward ? kTileSpheres : kTileSpheresStack;
+    float * const cone = reinterpret_cast<float *>(sph + kTile);
+    BlockEnv<kLibMath, kFused> env{A, sph, cone, kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool(), PixelRing()};
+    if constexpr (kFused)
+      env.ring.init(reinterpret_cast<unsigned char *>(cone + kTile) + (threadIdx.x / 64u) * ring_bytes_per_wave(A.ring_slots), A.ring_slots);
     __syncthreads();
-    BlockEnv<kLibMath> env{A, sph, reinterpret_cast<float *>(sph + (kForward ? kTileSpheres : kTileSpheresStack)), kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool()};
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   }
   else
@@ -545,7 +831,10 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
-    WaveEnv<kLibMath> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool()};
+    WaveEnv<kLibMath, kFused> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool(), PixelRing()};
+    if constexpr (kFused)
+      env.ring.init(reinterpret_cast<unsigned char *>(batch + (kBlock / 64u) * kItemBatch) + (threadIdx.x / 64u) * ring_bytes_per_wave(A.ring_slots),
+                    A.ring_slots);
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
@@ -557,7 +846,7 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 
 // The same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).  LDS: [path stacks, unless
 // kForward][jitter table].
-template <bool kForward, bool kOneLight, bool kLibMath = false>
+template <bool kForward, bool kOneLight, bool kLibMath = false, bool kFused = false>
 __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPerSimd) void trace_kernel_grid(TraceArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -570,7 +859,9 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
 #if defined(RT_PROFILE_REGIONS)
   cnt.last_tick = __builtin_amdgcn_s_memtime();
 #endif
-  GridEnv<kLibMath> env{A, jitter, ItemPool()};
+  GridEnv<kLibMath, kFused> env{A, jitter, ItemPool(), PixelRing()};
+  if constexpr (kFused)
+    env.ring.init(reinterpret_cast<unsigned char *>(jitter + RT_JITTER_FLOATS) + (threadIdx.x / 64u) * ring_bytes_per_wave(A.ring_slots), A.ring_slots);
   trace_loop<kForward, true, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
   flush_counters(A, cnt);
 }
@@ -806,8 +1097,10 @@ struct Library
     size_t partial_bytes = 0;
     f4 * camtab = nullptr;
     size_t camtab_entries = 0;
-    unsigned long long * stats = nullptr;  // kStatsWords + 1 words, for callers that pass no d_stats
+    unsigned long long * stats = nullptr;  // kStatsWordsAll words, for callers that pass no d_stats
     unsigned long long last_use = 0;       // for handing the least recently used set to a ninth stream
+    int callers = 0;                       // calls that hold this set right now (under Library::mutex)
+    std::mutex use;                        // held while a call grows the set and enqueues on it
   };
   unsigned long long workspace_clock = 0;
   static constexpr int kWorkspaces = 8;
@@ -839,13 +1132,18 @@ struct rt_hip_scene
                             // radii and light vectors between 2^-40 and 2^40 long, roughness at most 2^40
   // Blocks per compute unit of the trace kernel this scene is traced with, asked of the runtime once per kernel
   // variant ([1]: the grid walk) and LDS size rather than on every launch.
+  // ... together with the number of windows a wave may keep unfinished when the pixel sums are taken inside the
+  // kernel (TraceArgs::ring_slots): as many as fit the LDS the blocks of a compute unit share without costing a
+  // block; 0: none fit.  Filled under the mutex: one scene may be traced from several threads at once.
   struct Occupancy
   {
-    size_t lds = ~(size_t)0;
+    size_t lds = ~(size_t)0;  // of the launch without a ring
     bool tiled = false;
     int per_cu = 0;
+    uint32_t ring_slots = 0;
   };
   mutable Occupancy occupancy[4];
+  mutable std::mutex occupancy_mutex;
   // uniform grid for RT_HIP_FLAG_GRID traces (scenes of at least kGridMinSpheres spheres)
   bool has_grid = false;
   uint32_t * d_grid_start = nullptr;
@@ -867,7 +1165,7 @@ struct rt_hip_job
   float * d_rgb = nullptr;  // the finished image: the accumulate and resolve passes follow the trace on its stream
   f4 * d_camtab = nullptr;  // this frame's camera table
   size_t camtab_entries = 0;
-  unsigned long long * d_stats = nullptr;  // kStatsWords counters + the queue counter behind them
+  unsigned long long * d_stats = nullptr;  // kStatsWords counters, the queue counter and the error word behind them
   hipEvent_t start = nullptr, stop = nullptr;  // directly around the trace kernel
   hipEvent_t done = nullptr;                   // after the resolve pass: d_rgb is complete
   // Snapshots of the running frame have an image of their own (the passes that produce d_rgb may run at the same
@@ -877,6 +1175,7 @@ struct rt_hip_job
   float * h_snap = nullptr;
   uint32_t * h_cancel = nullptr;  // pinned host word the kernel polls; written by rt_hip_job_cancel
   bool cancelled = false;
+  bool fused = false;  // the trace kernel took the pixel sums itself: d_partial holds no column sums
 };
 
 namespace
@@ -932,22 +1231,24 @@ bool uses_column_masks(const rt_hip_scene * sc)
 
 // Path stacks (scenes whose paths cannot be accumulated forward) + either the resident scene (filter, camera
 // table, exact records, materials, lights, one prepared-column table per wave) or one staging tile.
-size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags)
+// ring_slots: windows per wave whose column sums the kernel keeps (0: the column sums go to memory).
+size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags, uint32_t ring_slots)
 {
   size_t bytes = (sc->forward_ok ? 0u : sizeof(f4) * (size_t)(RT_MAX_DEPTH * kBlock)) + sizeof(float) * RT_JITTER_FLOATS;
   if (uses_grid(sc, flags))
-    return bytes;
-  if (is_tiled(sc))
+    ;
+  else if (is_tiled(sc))
     bytes += (sizeof(f4) + sizeof(float)) * (size_t)(sc->forward_ok ? kTileSpheres : kTileSpheresStack);
   else
     bytes = resident_lds_bytes(sc);
+  bytes += (size_t)(kBlock / 64) * ring_bytes_per_wave(ring_slots);
   return std::max<size_t>(bytes, 16u);
 }
 
 // The kernel for a scene: resident / tiled / grid walk, stack or forward accumulation; the forward kernels of
 // the resident and the grid path also come specialised for scenes with exactly one light.
 template <class Launch>
-auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_math, Launch && go)
+auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_math, bool fused, Launch && go)
 {
   bool const one = sc->n_lights == 1u;
   if (library_math)
@@ -964,18 +1265,27 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_mat
   {
     if (!sc->forward_ok)
       return go(trace_kernel_grid<false, false>);
+    if (fused)
+      return one ? go(trace_kernel_grid<true, true, false, true>) : go(trace_kernel_grid<true, false, false, true>);
     return one ? go(trace_kernel_grid<true, true>) : go(trace_kernel_grid<true, false>);
   }
   if (is_tiled(sc))
   {
     if (!sc->forward_ok)
       return go(trace_kernel<true, false, false>);
+    if (fused)
+      return one ? go(trace_kernel<true, true, true, false, true>) : go(trace_kernel<true, true, false, false, true>);
     return one ? go(trace_kernel<true, true, true>) : go(trace_kernel<true, true, false>);
   }
   if (!sc->forward_ok)
     return go(trace_kernel<false, false, false>);
+  if (fused)
+    return one ? go(trace_kernel<false, true, true, false, true>) : go(trace_kernel<false, true, false, false, true>);
   return one ? go(trace_kernel<false, true, true>) : go(trace_kernel<false, true, false>);
 }
+
+// Which scenes have kernels that take the pixel sums themselves.
+bool has_fused_kernel(const rt_hip_scene * sc, bool library_math) { return sc->forward_ok && !library_math; }
 
 // The short exact sequences need the scene and the camera within 2^40 of the origin and a near plane between 2^-20
 // and 2^40 (rt_core.h near_root, inv_sqrt_rn); otherwise, and with RT_HIP_LIBRARY_MATH set (any value, for
@@ -997,22 +1307,61 @@ bool needs_library_math(const rt_hip_scene * sc, const rt_hip_camera * camera)
 // 0.41 ms, 1920x1080 2x2 1.04 -> 1.00 ms); never below one wave per SIMD.  Tiled scenes keep the full grid: their
 // blocks move in step and the samples cost a hundred times as much.
 constexpr unsigned long long kSamplesPerLane = 36;
-int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, bool library_math, unsigned long long items,
-                      unsigned long long samples, bool leave_room)
+// Blocks per compute unit of the trace kernel for this scene, and the ring it can afford (rt_hip_scene::Occupancy).
+// RT_HIP_NO_FUSE (any value): no ring, the column sums go to memory and the accumulate pass adds them, for
+// comparisons; RT_HIP_RING_SLOTS=n: at most n slots.
+rt_hip_scene::Occupancy launch_shape(const rt_hip_scene * sc, uint32_t flags, bool library_math)
 {
-  size_t const lds = lds_bytes(sc, flags);
+  size_t const lds = lds_bytes(sc, flags, 0u);
+  uint32_t most = std::getenv("RT_HIP_NO_FUSE") ? 0u : kRingMaxSlots;
+  if (const char * v = std::getenv("RT_HIP_RING_SLOTS"))
+    most = std::min<uint32_t>(most, (uint32_t)std::strtoul(v, nullptr, 10));
+  std::lock_guard<std::mutex> lock(sc->occupancy_mutex);
   rt_hip_scene::Occupancy & cached = sc->occupancy[(uses_grid(sc, flags) ? 1 : 0) + (library_math ? 2 : 0)];
   if (cached.lds != lds || cached.tiled != is_tiled(sc) || cached.per_cu < 1)
   {
-    int asked = 0;
-    hipError_t const e = with_trace_kernel(sc, flags, library_math, [&](auto kernel) {
-      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked, kernel, kBlock, lds);
-    });
+    auto blocks_with = [&](size_t bytes, bool fused) {
+      int asked = 0;
+      hipError_t const e = with_trace_kernel(sc, flags, library_math, fused, [&](auto kernel) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked, kernel, kBlock, bytes);
+      });
+      return (e != hipSuccess || asked < 1) ? 0 : asked;
+    };
     cached.lds = lds;
     cached.tiled = is_tiled(sc);
-    cached.per_cu = (e != hipSuccess || asked < 1) ? 1 : asked;
+    cached.per_cu = std::max(blocks_with(lds, false), 1);
+    cached.ring_slots = 0u;
+    for (uint32_t slots = kRingMaxSlots; has_fused_kernel(sc, library_math) && slots >= kRingMinSlots; --slots)
+    {
+      size_t const with_ring = lds_bytes(sc, flags, slots);
+      if (with_ring <= g_lib.lds_per_block && blocks_with(with_ring, true) >= cached.per_cu)
+      {
+        cached.ring_slots = slots;
+        break;
+      }
+    }
   }
-  int const per_cu = cached.per_cu;
+  rt_hip_scene::Occupancy shape = cached;
+  shape.ring_slots = std::min(shape.ring_slots, most);
+  if (shape.ring_slots < kRingMinSlots)
+    shape.ring_slots = 0u;
+  return shape;
+}
+
+// The pixel sums of a frame are taken inside the trace kernel when a window of the work queue holds whole pixels
+// (samples_in_row divides kItemBatch) and the scene's launch has room for a ring.
+uint32_t frame_ring_slots(const rt_hip_scene * sc, const rt_hip_trace_params * p, bool library_math)
+{
+  uint32_t const s = p->samples_in_row;
+  if (s == 0u || s > kItemBatch || (kItemBatch % s) != 0u)
+    return 0u;
+  return launch_shape(sc, p->flags, library_math).ring_slots;
+}
+
+int persistent_blocks(const rt_hip_scene * sc, uint32_t flags, bool library_math, unsigned long long items,
+                      unsigned long long samples, bool leave_room)
+{
+  int const per_cu = launch_shape(sc, flags, library_math).per_cu;
   long long blocks = (long long)per_cu * std::max(g_lib.compute_units, 1);
   if (leave_room && per_cu >= kWavesPerSimdForward)
     blocks -= kSnapshotReserveBlocks;
@@ -1083,11 +1432,10 @@ size_t share_bytes(const rt_hip_trace_params * p)
 // Column sums: 12 bytes per column of the frame, whatever the slice (every slice visits every column).
 size_t partial_bytes(const rt_hip_trace_params * p) { return 3 * sizeof(float) * (size_t)frame_items(p); }
 
-// A trace's output buffer: the column sums, then (256-byte aligned) the room sample sharing needs.
-size_t trace_buffer_bytes(const rt_hip_trace_params * p)
-{
-  return ((partial_bytes(p) + 255u) & ~(size_t)255u) + share_bytes(p);
-}
+// A trace's work buffer: the column sums -- unless the kernel takes the pixel sums itself (`fused`) -- then
+// (256-byte aligned) the room sample sharing needs.
+size_t share_offset(const rt_hip_trace_params * p, bool fused) { return fused ? 0u : ((partial_bytes(p) + 255u) & ~(size_t)255u); }
+size_t trace_buffer_bytes(const rt_hip_trace_params * p, bool fused) { return share_offset(p, fused) + share_bytes(p); }
 
 int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p)
 {
@@ -1110,16 +1458,30 @@ int validate(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_
   return RT_HIP_OK;
 }
 
-// Enqueues, on `stream`: the set-up kernel (camera table for this frame's camera, counters reset), the trace kernel and, with
-// sample sharing, the fold pass.  d_partial receives the column sums of this slice; `capacity` is the size of
-// the buffer behind it: sample sharing is on when it has room for the records and colours behind the column
-// sums (trace_buffer_bytes). d_stats points at kStatsWords counters followed by the
-// queue counter (one 8-byte slot).  When events are given they are recorded directly around the trace
-// kernel.  d_camtab (scene->n_padded entries) belongs to the caller's job or workspace, so one scene carries any
-// number of traces at a time.
+int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream,
+                  bool beside_trace = false);
+
+// What a trace writes to, besides the caller's stream.
+struct TraceTarget
+{
+  float * work = nullptr;       // column sums (frames whose pixel sums the kernel does not take itself), then the room
+  size_t work_bytes = 0;        // of sample sharing: trace_buffer_bytes; sharing is on when its room fits
+  float * planes = nullptr;     // 3 x pixels: the slice's pixel sums
+  f4 * camtab = nullptr;        // scene->n_padded entries; belongs to the caller's job or workspace, so one scene
+                                // carries any number of traces at a time
+  unsigned long long * stats = nullptr;  // kStatsWordsAll words: counters, queue word, error word
+  bool want_stats = false;
+  const uint32_t * cancel = nullptr;
+  bool clear_first = false;     // a job: what snapshots read (pixel sums, or column sums) starts from zero
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // recorded directly around the trace kernel (and its fold pass)
+  bool fused = false;           // out: the kernel took the pixel sums itself
+};
+
+// Enqueues, on `stream`: the set-up kernel (camera table for this frame's camera, counters reset), the trace kernel and
+// what completes the slice's pixel sums in t.planes -- nothing when the kernel takes them itself, else the fold pass of
+// sample sharing and the accumulate pass over the column sums.
 int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const rt_hip_trace_params * p,
-                 float * d_partial, unsigned long long * d_stats, bool want_stats, hipStream_t stream,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, size_t capacity, const uint32_t * d_cancel, f4 * d_camtab)
+                 TraceTarget & t, hipStream_t stream)
 {
   TraceArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -1129,7 +1491,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.aux_rw = scene->d_aux_rw;
   a.aux_cone = scene->d_aux_cone;
   a.centre = scene->centre;
-  a.camtab = d_camtab;
+  a.camtab = t.camtab;
   a.sphere_mat = scene->d_sphere_mat;
   a.materials = scene->d_materials;
   a.lights = scene->d_lights;
@@ -1143,7 +1505,9 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   a.cone_cos = scene->cone0.cos_m;
   a.cone_sin = scene->cone0.sin_m;
   a.cone_inv_cos = scene->cone0.cos_m > 0.0f ? 1.0f / scene->cone0.cos_m : 1.0f;
-  a.partial = d_partial;
+  a.partial = t.work;
+  a.planes = t.planes;
+  a.n_pixels = p->width * p->height;
   a.n_items = p->width * p->height * p->samples_in_row;
   a.queue_items = a.n_items;
   if (pixel_runs(p))
@@ -1152,9 +1516,10 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     set_pixel_runs(a, kRunPixels);
   }
   unsigned long long const per_column = std::max<uint32_t>(1u, a.s_row / a.slice_count);  // samples of a column traced here
-  a.stats = want_stats ? d_stats : nullptr;
-  a.queue_counter = reinterpret_cast<uint32_t *>(d_stats + kStatsWords);
-  a.cancel = d_cancel ? d_cancel : g_lib.never_cancel;
+  a.stats = t.want_stats ? t.stats : nullptr;
+  a.queue_counter = reinterpret_cast<uint32_t *>(t.stats + kStatsWords);
+  a.ring_errors = t.stats + kStatsWords + 1u;
+  a.cancel = t.cancel ? t.cancel : g_lib.never_cancel;
   unsigned long long const cost = uses_grid(scene, p->flags) ? 1u : std::max<unsigned long long>(1u, scene->n_spheres / 64u);
   a.batch_items = batch_items(a.queue_items, per_column, g_lib.compute_units, cost);
   if (const char * v = std::getenv("RT_HIP_BATCH_ITEMS"))  // experiments: reservation size in items (a multiple of 64)
@@ -1179,47 +1544,62 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     a.grid_inv_cell = 1.0f / scene->grid_cell;
   }
   bool const library_math = needs_library_math(scene, camera);
+  a.ring_slots = frame_ring_slots(scene, p, library_math);
+  t.fused = a.ring_slots != 0u;
+  if (t.fused)
+    for (a.s_shift = 0u; (1u << a.s_shift) < a.s_row; ++a.s_shift)
+      ;
+  else if (t.work_bytes < partial_bytes(p))
+    return fail(RT_HIP_ERR_INVALID, "internal: work buffer smaller than the frame's column sums");
   a.column_masks = (uses_column_masks(scene) && !uses_grid(scene, p->flags)) ? 1u : 0u;
   a.col_delta = a.column_masks ? column_delta(a) : 0.0f;
   bool const leave_room = (p->flags & RT_HIP_FLAG_LEAVE_ROOM) != 0u ||
-                          (d_cancel != nullptr && (unsigned long long)a.queue_items * per_column >= kSnapshotRoomSamples);
+                          (t.cancel != nullptr && (unsigned long long)a.queue_items * per_column >= kSnapshotRoomSamples);
   int const blocks = persistent_blocks(scene, p->flags, library_math, std::max<uint32_t>(a.queue_items, 1u),
                                        (unsigned long long)a.queue_items * per_column, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
-  size_t const lds = lds_bytes(scene, p->flags);
+  size_t const lds = lds_bytes(scene, p->flags, a.ring_slots);
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
   size_t const lanes = (size_t)blocks * kBlock;
-  size_t const share_at = (partial_bytes(p) + 255u) & ~(size_t)255u;
-  if (capacity >= share_at + share_bytes_for(lanes, share_depth(p)) && !share_disabled())
+  size_t const share_at = share_offset(p, t.fused);
+  if (t.work != nullptr && t.work_bytes >= share_at + share_bytes_for(lanes, share_depth(p)) && !share_disabled())
   {
-    unsigned char * const base = reinterpret_cast<unsigned char *>(d_partial) + share_at;
+    unsigned char * const base = reinterpret_cast<unsigned char *>(t.work) + share_at;
     a.split_count = reinterpret_cast<uint32_t *>(base);
     a.splits = reinterpret_cast<u4 *>(base + 16);
     a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
-    a.shared_off = (size_t)(a.shared - d_partial);
+    a.shared_off = (size_t)(a.shared - t.work);
     a.share_depth = share_depth(p);
   }
+  // What must start from zero: the sums of the pixels this slice does not trace (slices by runs of pixels: the kernel
+  // writes its own pixels only) and whatever a snapshot may read before the kernel has written it.
+  if (t.fused && (t.clear_first || pixel_runs(p)))
+    RT_CHECK(hipMemsetAsync(t.planes, 0, 3 * sizeof(float) * (size_t)a.n_pixels, stream));
+  if (!t.fused && t.clear_first)
+    RT_CHECK(hipMemsetAsync(t.work, 0, partial_bytes(p), stream));
   {
     int const tab_blocks = std::max(1, (int)((scene->n_padded + 255u) / 256u));
-    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_spheres, scene->d_aux_rw, d_camtab,
-                       scene->n_padded, a.cam_pos, a.col_delta, d_stats, (uint32_t)(kStatsWords + 1), a.split_count);
+    hipLaunchKernelGGL(camtab_kernel, dim3(tab_blocks), dim3(256), 0, stream, scene->d_spheres, scene->d_aux_rw, t.camtab,
+                       scene->n_padded, a.cam_pos, a.col_delta, t.stats, kStatsWordsAll, a.split_count);
     RT_CHECK(hipGetLastError());
   }
-  if (ev_start)
-    RT_CHECK(hipEventRecord(ev_start, stream));
-  (void)with_trace_kernel(scene, p->flags, library_math, [&](auto kernel) {
+  if (t.ev_start)
+    RT_CHECK(hipEventRecord(t.ev_start, stream));
+  (void)with_trace_kernel(scene, p->flags, library_math, t.fused, [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, stream, a);
     return hipSuccess;
   });
   RT_CHECK(hipGetLastError());
-  if (a.share_depth != 0u)
+  if (!t.fused && a.share_depth != 0u)
   {
-    hipLaunchKernelGGL(fold_kernel, dim3(std::min(blocks, 256)), dim3(256), 0, stream, d_partial, a.shared, a.splits,
+    hipLaunchKernelGGL(fold_kernel, dim3(std::min(blocks, 256)), dim3(256), 0, stream, t.work, a.shared, a.splits,
                        a.split_count, a.s_row, a.slice_count);
     RT_CHECK(hipGetLastError());
   }
-  if (ev_stop)
-    RT_CHECK(hipEventRecord(ev_stop, stream));
+  if (t.ev_stop)
+    RT_CHECK(hipEventRecord(t.ev_stop, stream));
+  if (!t.fused)
+    return launch_colsum(t.work, t.planes, p, stream);
   return RT_HIP_OK;
 }
 
@@ -1227,7 +1607,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
 // Measured on a 3840x2160 job: the lane-per-pixel kernel does (12 ms per snapshot), the LDS kernel, 50 KB a block,
 // waits for the frame's end.
 int launch_colsum(const float * d_partial, float * d_planes, const rt_hip_trace_params * p, hipStream_t stream,
-                  bool beside_trace = false)
+                  bool beside_trace)
 {
   uint32_t const n = p->width * p->height;
   uint32_t const own_stride = pixel_runs(p) ? p->slice_count : 1u;
@@ -1307,6 +1687,12 @@ void free_job(rt_hip_job * job)
 {
   if (job == nullptr)
     return;
+  // what only a snapshot needed goes back at once: a parked job holds the buffers every frame needs, no more
+  if (job->d_snap_planes) (void)hipFree(job->d_snap_planes);
+  if (job->d_snap_rgb) (void)hipFree(job->d_snap_rgb);
+  if (job->h_snap) (void)hipHostFree(job->h_snap);
+  job->d_snap_planes = job->d_snap_rgb = nullptr;
+  job->h_snap = nullptr;
   rt_hip_job * evicted = job;
   {
     std::lock_guard<std::mutex> lock(g_lib.mutex);
@@ -1321,9 +1707,8 @@ void free_job(rt_hip_job * job)
 }
 
 // A job object with buffers for `params`: the spare one if it fits, else a fresh one.
-rt_hip_job * acquire_job(const rt_hip_trace_params * params, size_t camtab_entries, hipError_t & e)
+rt_hip_job * acquire_job(const rt_hip_trace_params * params, size_t need, size_t camtab_entries, hipError_t & e)
 {
-  size_t const need = trace_buffer_bytes(params);
   size_t const pixels = (size_t)params->width * params->height;
   camtab_entries = std::max<size_t>(camtab_entries, 1);
   rt_hip_job * job = nullptr;
@@ -1359,7 +1744,7 @@ rt_hip_job * acquire_job(const rt_hip_trace_params * params, size_t camtab_entri
   if (e == hipSuccess) e = hipEventCreate(&job->done);
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_planes, 3 * pixels * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)&job->d_rgb, 3 * pixels * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&job->d_stats, sizeof(unsigned long long) * kStatsWordsAll);
   if (e == hipSuccess) e = hipEventCreate(&job->start);
   if (e == hipSuccess) e = hipEventCreate(&job->stop);
   if (e == hipSuccess) e = hipHostMalloc((void **)&job->h_cancel, 64, hipHostMallocMapped);
@@ -1394,7 +1779,14 @@ static void release_device_state()
     if (w.partial) (void)hipFree(w.partial);
     if (w.camtab) (void)hipFree(w.camtab);
     if (w.stats) (void)hipFree(w.stats);
-    w = Library::Workspace();
+    w.stream = nullptr;
+    w.used = false;
+    w.partial = nullptr;
+    w.partial_bytes = 0;
+    w.camtab = nullptr;
+    w.camtab_entries = 0;
+    w.stats = nullptr;
+    w.last_use = 0;
   }
   if (g_lib.never_cancel) (void)hipFree(g_lib.never_cancel);
   if (g_lib.jitter_tab) (void)hipFree(g_lib.jitter_tab);
@@ -1467,9 +1859,8 @@ int rt_hip_init(int device)
     RT_CHECK(hipMalloc((void **)&g_lib.jitter_tab, sizeof(tab)));
     RT_CHECK(hipMemcpy(g_lib.jitter_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
-  int const rc = resolve_static_scratch(target);
-  if (rc != RT_HIP_OK)
-    return rc;
+  // (without the address only rt_hip_trace_device_static is lost, and it says so itself)
+  (void)resolve_static_scratch(target);
   g_lib.ready = true;
   return RT_HIP_OK;
 }
@@ -1628,25 +2019,33 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
     return rc;
 
   hipError_t e = hipSuccess;
-  rt_hip_job * job = acquire_job(params, scene->n_padded, e);
+  bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
+  rt_hip_job * job = acquire_job(params, trace_buffer_bytes(params, fused), scene->n_padded, e);
   if (job == nullptr)
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   uint32_t * d_cancel = nullptr;
   e = hipHostGetDevicePointer((void **)&d_cancel, job->h_cancel, 0);
-  // Unfinished columns read as black in snapshots.
-  if (e == hipSuccess) e = hipMemsetAsync(job->d_partial, 0, partial_bytes(params), g_lib.stream);
   if (e != hipSuccess)
   {
     free_job(job);
     return fail(RT_HIP_ERR_DEVICE, "job set-up", e);
   }
-  rc = launch_trace(scene, camera, params, job->d_partial, job->d_stats, true, g_lib.stream, job->start,
-                    job->stop, job->partial_size, d_cancel, job->d_camtab);
-  // The accumulate and resolve passes follow the trace on its stream, so the image is complete when `done` fires
+  TraceTarget t;
+  t.work = job->d_partial;
+  t.work_bytes = job->partial_size;
+  t.planes = job->d_planes;
+  t.camtab = job->d_camtab;
+  t.stats = job->d_stats;
+  t.want_stats = true;
+  t.cancel = d_cancel;
+  t.clear_first = true;  // unfinished pixels read as black in snapshots
+  t.ev_start = job->start;
+  t.ev_stop = job->stop;
+  // The pixel sums and the resolve pass follow the trace on its stream, so the image is complete when `done` fires
   // and rt_hip_job_finish only has the download left -- on the copy stream, where it runs beside whatever frame
   // the trace stream has started next.
-  if (rc == RT_HIP_OK)
-    rc = launch_colsum(job->d_partial, job->d_planes, params, g_lib.stream);
+  rc = launch_trace(scene, camera, params, t, g_lib.stream);
+  job->fused = t.fused;
   if (rc == RT_HIP_OK)
     rc = launch_resolve(job->d_planes, job->d_rgb, params->width, params->height, params->samples_in_row, g_lib.stream);
   if (rc == RT_HIP_OK && (e = hipEventRecord(job->done, g_lib.stream)) != hipSuccess)
@@ -1681,7 +2080,8 @@ int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
   size_t const bytes = 3 * pixels * sizeof(float);
   if (job->h_snap == nullptr)
   {
-    hipError_t e = hipMalloc((void **)&job->d_snap_planes, bytes);
+    // (the first snapshot of a job allocates: device-synchronising calls, made while the trace runs)
+    hipError_t e = job->fused ? hipSuccess : hipMalloc((void **)&job->d_snap_planes, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&job->d_snap_rgb, bytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&job->h_snap, bytes, hipHostMallocDefault);
     if (e != hipSuccess)
@@ -1693,11 +2093,18 @@ int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
       return fail(RT_HIP_ERR_DEVICE, "snapshot buffers", e);
     }
   }
-  // Accumulate, resolve and download on the copy stream: they run beside the trace kernel and never wait for it.
-  // Columns the trace has not finished yet still hold the zeros they were cleared to.
-  int rc = launch_colsum(job->d_partial, job->d_snap_planes, &job->params, g_lib.copy_stream, true);
+  // Resolve (after the accumulate pass, where the kernel leaves column sums) and download on the copy stream: they
+  // run beside the trace kernel and never wait for it.  Pixels (columns) the trace has not finished yet still hold
+  // the zeros they were cleared to.
+  int rc = RT_HIP_OK;
+  const float * sums = job->d_planes;
+  if (!job->fused)
+  {
+    rc = launch_colsum(job->d_partial, job->d_snap_planes, &job->params, g_lib.copy_stream, true);
+    sums = job->d_snap_planes;
+  }
   if (rc == RT_HIP_OK)
-    rc = launch_resolve(job->d_snap_planes, job->d_snap_rgb, job->params.width, job->params.height,
+    rc = launch_resolve(sums, job->d_snap_rgb, job->params.width, job->params.height,
                         job->params.samples_in_row, g_lib.copy_stream);
   if (rc != RT_HIP_OK)
     return rc;
@@ -1738,12 +2145,14 @@ int rt_hip_job_finish(rt_hip_job * job, float * rgb, rt_hip_stats * stats)
   }
   if (rc == RT_HIP_OK && stats != nullptr)
   {
-    unsigned long long h[kStatsWords] = {0};
+    unsigned long long h[kStatsWordsAll] = {0};
     std::memset(stats, 0, sizeof(*stats));
     e = hipMemcpyAsync(h, job->d_stats, sizeof(h), hipMemcpyDeviceToHost, g_lib.copy_stream);
     if (e == hipSuccess)
       e = hipStreamSynchronize(g_lib.copy_stream);
-    if (e == hipSuccess)
+    if (e == hipSuccess && h[kStatsWords + 1u] != 0ull)
+      rc = fail(RT_HIP_ERR_DEVICE, "internal: a wave gave up waiting for a free window slot; the image is incomplete");
+    else if (e == hipSuccess)
     {
       read_stats(h, stats);
       float ms = 0.0f;
@@ -1770,32 +2179,52 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
     return fail(RT_HIP_ERR_INVALID, "null output");
   hipStream_t const hs = static_cast<hipStream_t>(stream);
   // This stream's workspace: calls on one stream are ordered and share it, calls on different streams overlap.
-  // The lock is held until the work is enqueued, so a workspace cannot change hands under a call that uses it.
-  std::lock_guard<std::mutex> lock(g_lib.mutex);
+  // The library's lock is held only while the set is picked and marked as held; growing it and enqueueing on it
+  // happen under the set's own lock, so a call that has to wait for the device (a set that grows or changes
+  // hands) holds up no call on another stream.
   Library::Workspace * ws = nullptr;
-  for (Library::Workspace & w : g_lib.workspaces)
-    if (w.used && w.stream == hs)
-      ws = &w;
-  for (Library::Workspace & w : g_lib.workspaces)
-    if (ws == nullptr && !w.used)
-    {
-      w.used = true;
-      w.stream = hs;
-      ws = &w;
-    }
-  if (ws == nullptr)
+  bool takeover = false;
   {
-    // every set belongs to some stream: the least recently used one changes hands once the device is idle
-    // (its old stream may no longer exist, so there is nothing narrower to wait for)
-    ws = &g_lib.workspaces[0];
+    std::lock_guard<std::mutex> lock(g_lib.mutex);
     for (Library::Workspace & w : g_lib.workspaces)
-      if (w.last_use < ws->last_use)
+      if (w.used && w.stream == hs)
         ws = &w;
-    RT_CHECK(hipDeviceSynchronize());
-    ws->stream = hs;
+    for (Library::Workspace & w : g_lib.workspaces)
+      if (ws == nullptr && !w.used)
+      {
+        w.used = true;
+        w.stream = hs;
+        ws = &w;
+      }
+    if (ws == nullptr)
+    {
+      // every set belongs to some stream: the least recently used one that no call holds changes hands once the
+      // device is idle (its old stream may no longer exist, so there is nothing narrower to wait for)
+      for (Library::Workspace & w : g_lib.workspaces)
+        if (w.callers == 0 && (ws == nullptr || w.last_use < ws->last_use))
+          ws = &w;
+      if (ws == nullptr)
+        return fail(RT_HIP_ERR_INVALID, "rt_hip_trace_device: more than eight calls on different streams at the same time");
+      ws->stream = hs;
+      takeover = true;
+    }
+    ws->last_use = ++g_lib.workspace_clock;
+    ws->callers += 1;
   }
-  ws->last_use = ++g_lib.workspace_clock;
-  size_t const need = trace_buffer_bytes(params);
+  struct Release
+  {
+    Library::Workspace * ws;
+    ~Release()
+    {
+      std::lock_guard<std::mutex> lock(g_lib.mutex);
+      ws->callers -= 1;
+    }
+  } release{ws};
+  std::lock_guard<std::mutex> use(ws->use);
+  if (takeover)
+    RT_CHECK(hipDeviceSynchronize());
+  bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
+  size_t const need = trace_buffer_bytes(params, fused);
   if (ws->partial_bytes < need)
   {
     if (ws->partial != nullptr)
@@ -1825,14 +2254,17 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
   if (st == nullptr)
   {
     if (ws->stats == nullptr)
-      RT_CHECK(hipMalloc((void **)&ws->stats, sizeof(unsigned long long) * (kStatsWords + 1)));
+      RT_CHECK(hipMalloc((void **)&ws->stats, sizeof(unsigned long long) * kStatsWordsAll));
     st = ws->stats;
   }
-  int rc2 = launch_trace(scene, camera, params, ws->partial, st, d_stats != nullptr, hs, nullptr, nullptr,
-                         ws->partial_bytes, nullptr, ws->camtab);
-  if (rc2 == RT_HIP_OK)
-    rc2 = launch_colsum(ws->partial, d_sum_planes, params, hs);
-  return rc2;
+  TraceTarget t;
+  t.work = ws->partial;
+  t.work_bytes = ws->partial_bytes;
+  t.planes = d_sum_planes;
+  t.camtab = ws->camtab;
+  t.stats = st;
+  t.want_stats = d_stats != nullptr;
+  return launch_trace(scene, camera, params, t, hs);
 }
 
 int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera * camera,
@@ -1850,28 +2282,30 @@ int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera *
     return fail(RT_HIP_ERR_DEVICE, "the static scratch array has no address on this device");
   if (scene->n_padded > kStaticMaxSpheres)
     return fail(RT_HIP_ERR_INVALID, "rt_hip_trace_device_static takes scenes of at most 16384 spheres");
-  if (partial_bytes(params) > kStaticPartialBytes)
+  // A frame whose pixel sums the kernel takes itself keeps no column sums: only the others are limited by the array.
+  bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
+  if (!fused && partial_bytes(params) > kStaticPartialBytes)
   {
-    char msg[256];
+    char msg[320];
     std::snprintf(msg, sizeof(msg),
                   "rt_hip_trace_device_static: width * height * samples_in_row is %llu, the limit is %llu (12 bytes per "
-                  "sub-sample column in a 64 MiB static array); rt_hip_trace_device has no such limit",
+                  "sub-sample column in a 64 MiB static array) for frames whose samples_in_row is not 1, 2, 4, 8, 16, 32 or "
+                  "64; rt_hip_trace_device has no such limit",
                   frame_items(params), (unsigned long long)(kStaticPartialBytes / (3u * sizeof(float))));
     return fail(RT_HIP_ERR_INVALID, msg);
   }
   hipStream_t const hs = static_cast<hipStream_t>(stream);
-  unsigned long long * const st =
-      d_stats ? static_cast<unsigned long long *>(d_stats) : reinterpret_cast<unsigned long long *>(base);
-  f4 * const camtab = reinterpret_cast<f4 *>(base + kStaticCamtabOffset);
-  float * const partial = reinterpret_cast<float *>(base + kStaticPartialOffset);
   // Nothing in the array has to be cleared by the host: the set-up kernel zeroes the counters, the queue word and the
   // sharing record count on the stream, every column sum of the frame is written by exactly one lane, and the
-  // camera table is rewritten for this frame.  Sample sharing is on when its room fits behind the column sums.
-  int rc2 = launch_trace(scene, camera, params, partial, st, d_stats != nullptr, hs, nullptr, nullptr,
-                         kStaticPartialBytes, nullptr, camtab);
-  if (rc2 == RT_HIP_OK)
-    rc2 = launch_colsum(partial, d_sum_planes, params, hs);
-  return rc2;
+  // camera table is rewritten for this frame.  Sample sharing is on when its room fits (behind the column sums).
+  TraceTarget t;
+  t.work = reinterpret_cast<float *>(base + kStaticPartialOffset);
+  t.work_bytes = kStaticPartialBytes;
+  t.planes = d_sum_planes;
+  t.camtab = reinterpret_cast<f4 *>(base + kStaticCamtabOffset);
+  t.stats = d_stats ? static_cast<unsigned long long *>(d_stats) : reinterpret_cast<unsigned long long *>(base);
+  t.want_stats = d_stats != nullptr;
+  return launch_trace(scene, camera, params, t, hs);
 }
 
 int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t width, uint32_t height,
@@ -1893,23 +2327,34 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
     return rc;
   if (launches == 0 || out_avg_ms == nullptr)
     return fail(RT_HIP_ERR_INVALID, "bad argument");
-  float * d_planes = nullptr;  // column sums
+  float * d_work = nullptr, * d_planes = nullptr;
   unsigned long long * d_stats = nullptr;
   f4 * d_camtab = nullptr;
   hipEvent_t start = nullptr, stop = nullptr;
-  hipError_t e = hipMalloc((void **)&d_planes, trace_buffer_bytes(params));
+  bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
+  size_t const work_bytes = trace_buffer_bytes(params, fused);
+  hipError_t e = hipMalloc((void **)&d_work, work_bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_planes, 3 * sizeof(float) * (size_t)params->width * params->height);
   if (e == hipSuccess) e = hipMalloc((void **)&d_camtab, sizeof(f4) * std::max<size_t>(scene->n_padded, 1));
-  if (e == hipSuccess) e = hipMalloc((void **)&d_stats, sizeof(unsigned long long) * (kStatsWords + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_stats, sizeof(unsigned long long) * kStatsWordsAll);
   if (e == hipSuccess) e = hipEventCreate(&start);
   if (e == hipSuccess) e = hipEventCreate(&stop);
   double total_ms = 0.0;
   for (uint32_t i = 0; e == hipSuccess && rc == RT_HIP_OK && i < launches; ++i)
   {
-    rc = launch_trace(scene, camera, params, d_planes, d_stats, true, g_lib.stream, start, stop,
-                      trace_buffer_bytes(params), nullptr, d_camtab);
+    TraceTarget t;
+    t.work = d_work;
+    t.work_bytes = work_bytes;
+    t.planes = d_planes;
+    t.camtab = d_camtab;
+    t.stats = d_stats;
+    t.want_stats = true;
+    t.ev_start = start;
+    t.ev_stop = stop;
+    rc = launch_trace(scene, camera, params, t, g_lib.stream);
     if (rc != RT_HIP_OK)
       break;
-    e = hipEventSynchronize(stop);
+    e = hipStreamSynchronize(g_lib.stream);
     if (e != hipSuccess)
       break;
     float ms = 0.0f;
@@ -1931,6 +2376,7 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
       }
     }
   }
+  if (d_work) (void)hipFree(d_work);
   if (d_planes) (void)hipFree(d_planes);
   if (d_stats) (void)hipFree(d_stats);
   if (d_camtab) (void)hipFree(d_camtab);

@@ -63,14 +63,21 @@ struct HostEnv
   bool any(bool p) { return p; }
   int count(bool p) { return p ? 1 : 0; }
   bool any_wave(bool p) { return p; }
+  void finish_columns(rtc::Lane & L, bool finishing)
+  {
+    if (finishing)
+      rtc::store_column(A, L, *this);
+  }
   void fetch_item(bool need, rtc::ItemInfo & info)
   {
     info.pos = rtc::RT_INVALID;
+    info.stalled = false;
     info.prepared = false;
     info.filter_tests = 0;
     if (!need || next >= A.n_items)
       return;
     info.pos = next++;
+    info.slot = info.pos;
     if (A.column_masks != 0u)
     {
       rtc::ColumnEntry const e = rtc::prepare_column(A, A.camtab, info.pos);
