@@ -30,7 +30,8 @@
  *   - A job belongs to one thread at a time: poll / snapshot / cancel / finish of one job must not overlap.
  *     Different jobs may be started and finished from different threads; they run on the library's trace stream
  *     in the order they were started.
- *   - rt_hip_trace_device may be called from several threads (one caller stream each).
+ *   - rt_hip_trace_device may be called from several threads (one caller stream each; a call that has to wait for
+ *     the device -- its stream's workspace grows, or changes hands -- holds up calls on that stream only).
  *   - rt_hip_trace_device_static shares one scratch array per GPU: calls that overlap on one GPU race.
  */
 #ifndef RT_HIP_H
@@ -76,6 +77,16 @@ extern "C" {
                                         slice's work is its share of the columns, not every column for a share of its
                                         samples (a 1/8 slice of the 1080p 16x16 frame: 2.4 ms instead of 3.2).  Same
                                         image. */
+
+#define RT_HIP_FLAG_KERNEL_SUMS 32u  /* the trace kernel adds up the pixels itself: every wave keeps the column sums of
+                                        the queue windows it works on in LDS and writes 12 bytes per pixel when a window
+                                        is done, instead of 12 bytes per sub-sample column for a separate accumulate
+                                        pass.  The same additions in the same order: same image, bit for bit.  Needs
+                                        samples_in_row in {1, 2, 4, 8, 16, 32, 64} and a scene whose paths need no stack
+                                        (ignored otherwise).  The kernel runs 3-5 % longer than with the pass, so this
+                                        is for callers short of memory or bandwidth: the workspace shrinks from 12 bytes
+                                        per column of the frame to the room of sample sharing (at most 54 MB), and
+                                        rt_hip_trace_device_static loses its frame-size limit. */
 
 /* Replaces CudaMaterial (rt_cuda/types_cuda.h): what Material::GetType/GetAlbedo/GetRoughness/
  * GetRefraction return (ray_tracing/material.hpp:20-26). */
@@ -174,7 +185,9 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
 int rt_hip_job_poll(rt_hip_job * job);
 
 /* Replaces ray_tracing_cuda::CopyOutputToBuffer (rt_cuda/rt_cuda.h:29): copies what has been rendered so
- * far (unfinished pixels are black) into rgb without stalling the trace. */
+ * far (unfinished pixels are black) into rgb without stalling the trace.  The first snapshot of a job allocates its
+ * image buffers (two device-synchronising calls, about 2 x 12 bytes per pixel on the device and 12 in pinned host
+ * memory); they are released when the job is finished. */
 int rt_hip_job_snapshot(rt_hip_job * job, float * rgb);
 
 /* Replaces ray_tracing_cuda::FinishRayTrace (rt_cuda/rt_cuda.h:32): waits for the frame, writes the final
@@ -205,11 +218,14 @@ int rt_hip_trace_device(const rt_hip_scene * scene, const rt_hip_camera * camera
  * call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
  * arguments, same output (bit for bit) as rt_hip_trace_device, but the scratch the kernels need (counters, camera
  * table, column sums, sample-sharing room) is a 64 MiB file-scope device array of the library instead of a
- * workspace: width * height * samples_in_row may not exceed 5 570 538 (12 bytes per sub-sample column; e.g.
- * 1024 x 768 at 2 x 2 ... 7 x 7 samples per pixel, or 1920 x 1080 at 2 x 2) and the scene may have at most 16384
- * spheres -- RT_HIP_ERR_INVALID with a message naming the limit otherwise.  Every call on a GPU uses that GPU's
- * one array, so calls that overlap on one GPU (on different streams or from different threads) race; calls on
- * one stream are ordered and safe.  Calls no hipMalloc / hipFree / hipHostMalloc. */
+ * workspace.  The scene may have at most 16384 spheres.  A frame whose column sums fit the array (12 bytes per
+ * sub-sample column: width * height * samples_in_row up to 5 570 538, e.g. 1024 x 768 at 2 x 2 ... 7 x 7 samples per
+ * pixel) is traced as rt_hip_trace_device traces it; a larger one is traced with RT_HIP_FLAG_KERNEL_SUMS where that
+ * flag applies (samples_in_row 1, 2, 4, 8, 16, 32 or 64: any frame size, e.g. 1920 x 1080 at 16 x 16) and refused
+ * with RT_HIP_ERR_INVALID and a message naming the limit where it does not.  Every call on a GPU uses that GPU's one
+ * array, so calls that overlap on one GPU (on different streams or from different threads) race; calls on one stream
+ * are ordered and safe.  Calls no hipMalloc / hipFree / hipHostMalloc and nothing that waits for the device, so it may
+ * be captured into a HIP graph (once the scene has been traced once outside a capture). */
 int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera * camera,
                                const rt_hip_trace_params * params, float * d_sum_planes, void * d_stats,
                                void * stream);

@@ -405,7 +405,9 @@ struct TraceArgs
 struct LaneCounters
 {
   uint32_t samples, queries, hits, shaded, exact_tests;
-  uint32_t filter_tests;  // rays, shadow cones or columns run through the filter; each is n_spheres tests
+  uint32_t filter_tests;  // rays and shadow cones run through the filter; each is n_spheres tests
+  uint32_t prepared;      // columns the lane's wave ran through the filter while preparing windows: the same number
+                          // in every lane of a wave (it counts once per wave)
   uint32_t cone_tests;    // spheres a shadow cone touched: each was intersected with the shadow rays still looking
   uint32_t trips, rounds;  // loop trips and stage-P rounds this lane sat through, busy or not
 #if defined(RT_PROFILE_REGIONS)
@@ -644,7 +646,8 @@ struct ItemInfo
   bool prepared;
   float sdx, dyp;
   uint32_t cm0, cm1, pixel, sx, sy0;
-  uint32_t filter_tests;  // columns this lane ran through the filter while preparing a batch (for anyone)
+  uint32_t filter_tests;  // columns the wave ran through the filter while preparing a window in this call (the same
+                          // number in every lane)
 };
 
 struct ColumnEntry
@@ -997,10 +1000,12 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //                     sphere tiles are re-staged inside the loop)
 //   count(p)          number of such lanes for which p holds
 //   any_wave(p)       true if p holds for any lane of the wave
-//   fetch_item(need, info)  hands a fresh work item to each lane that asks (info.pos == RT_INVALID when the
+//   fetch_item(L, need, info)  hands a fresh work item to each lane that asks (info.pos == RT_INVALID when the
 //                     slice is used up), prepared or not (see ItemInfo)
-//   finish_columns(L, finishing)  called by the whole wave when some lane's column (or shared sample) is complete:
-//                     the sums of the lanes with `finishing` leave their lanes (store_column, or the environment's
+//   column_sx(L)      sx of the lane's column: L.sx, or what an environment that names columns by their place in a
+//                     window derives from L.slot (one register fewer across the loop)
+//   finish_columns(L, finishing)  called by the whole wave in every round: the sums of the lanes with `finishing` (a
+//                     complete column or shared sample) leave their lanes (store_column, or the environment's
 //                     own pixel sums, TraceArgs::ring_slots)
 //   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i);  material(m, k) and
 //                     light(l, k): record k of material m / light l;  jitter_table()
@@ -1390,8 +1395,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       bool const need = L.alive && !L.has_hit && !L.shading;
       // Column (or shared sample) complete: its sum leaves the lane.
       bool const finishing = need && !L.need_item && L.sy >= L.sy_end;
-      if (env.any_wave(finishing))
-        env.finish_columns(L, finishing);
+      env.finish_columns(L, finishing);
       if (finishing)
         L.need_item = true;
       bool const ask = need && L.need_item;
@@ -1399,8 +1403,8 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       if (env.any(ask))
       {
         ItemInfo info;
-        env.fetch_item(ask, info);
-        cnt.filter_tests += info.filter_tests;
+        env.fetch_item(L, ask, info);
+        cnt.prepared += info.filter_tests;
         if (ask)
         {
           if (info.pos == RT_INVALID)
@@ -1440,7 +1444,7 @@ RT_FN void trace_loop(const TraceArgs & A, Env & env, f4 * stack, uint32_t strid
       RT_REGION(cnt, 0);
       if (env.any(active))
       {
-        uint32_t const s = L.sx * A.s_row + L.sy;
+        uint32_t const s = env.column_sx(L) * A.s_row + L.sy;
         f3 d = mk3(0.0f, 0.0f, 1.0f);
         if (active)
         {

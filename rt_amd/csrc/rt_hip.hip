@@ -96,6 +96,19 @@ static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 // ---------------------------------------------------------------- device side
 
+// The wave's index in its block as a scalar (threadIdx.x / 64 is the same in every lane, which the compiler cannot
+// know: taken from the first lane, what is computed from it lives in scalar registers).
+__device__ __forceinline__ uint32_t wave_in_block() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64u)); }
+// The lane's index, opaque to the compiler: what is computed from it is computed where it is used, not once ahead
+// of the kernel's main loop and kept in a register across it.
+__device__ __forceinline__ uint32_t lane_here()
+{
+  uint32_t lane = __lane_id();
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
+
 // Work items come from one frame-wide counter, but a wave only touches it once per A.batch_items items (a
 // multiple of kItemBatch chosen by the host: a single counter word sustains well under a hundred reservations
 // per microsecond, far fewer than the waves would ask for item by item, or even batch by batch when columns
@@ -109,7 +122,7 @@ __device__ unsigned long long g_wave_times[4 * kTimelineWaves];
 __device__ __forceinline__ void timeline_mark(uint32_t k)
 {
   uint32_t const wave = blockIdx.x * (kBlock / 64u) + threadIdx.x / 64u;
-  if (__lane_id() == 0 && wave < kTimelineWaves)
+  if (lane_here() == 0u && wave < kTimelineWaves)
     g_wave_times[4u * wave + k] = wall_clock64();
 }
 #endif
@@ -119,187 +132,240 @@ constexpr uint32_t kCancelPoll = 8;
 constexpr uint32_t kGuide = 16;
 
 // Pixel sums inside the trace kernel (TraceArgs::ring_slots).  Every wave keeps, in LDS, the column sums of the
-// windows it has handed out and not yet finished: `slots` windows of kItemBatch columns, each with a header
-//   [0] columns of the window that are items of the queue (0: the slot is free)   [1] columns done   [2] first pixel
-// A lane that finishes a column parks its sum in the window's slot and counts it; the lane that counts the last one
-// has the wave add each pixel's columns in increasing sx and write the pixel sums.  LDS operations of one wave are
-// carried out in program order, so a sum written in an earlier instruction (by any lane) is there when a later one
-// reads it; the wave-level fences only keep the compiler from moving the accesses.
+// windows it has opened and not yet finished: up to `slots` windows of kItemBatch columns, oldest (tail) to newest
+// (head), each with a header (columns of the window that are items of the queue, first pixel).  A lane that finishes
+// a column parks its sum in the window's slot.  Windows are finished in the order they were opened: the oldest one
+// is complete once all its columns have been handed out and no lane of the wave holds one of them any more -- one
+// ballot over Lane::slot, which names the window in bits 6..8 -- and then the wave adds each pixel's columns in
+// increasing sx and writes the pixel sums.  LDS operations of one wave are carried out in program order, so a sum
+// written in an earlier instruction (by any lane) is there when a later one reads it; the wave-level fences only
+// keep the compiler from moving the accesses.
 //
-// With sample sharing the sum of a column comes together in LDS too: `pending[l]` counts what is still missing of
-// the column lane l owns (the owner's own part and every sample handed to another lane), `meta[l]` holds where the
-// column belongs and the first sample that was handed out.  The colours of shared samples go through memory
-// (TraceArgs::shared) as they do for the fold pass; whoever brings pending[l] to zero adds them to the owner's part
-// in sample order -- the additions the owner would have made itself.
-constexpr uint32_t kRingHeaderWords = 4;
+// With sample sharing (the end of the queue) a lane that traces a sample of another lane's column holds that
+// column's window too (its slot names it), and the colour goes through memory (TraceArgs::shared) as it does for
+// the fold pass.  The owner leaves `meta[its lane]` = where the column belongs and the first sample that was handed
+// out; when the window is complete, the owner's lane adds the shared colours to its own part in sample order --
+// the additions the owner would have made itself -- before the pixels are summed.
+constexpr uint32_t kRingHeaderWords = 2;
 constexpr uint32_t kRingMaxSlots = 8;
 constexpr uint32_t kRingMinSlots = 2;
 constexpr uint32_t kRingStallLimit = 1u << 16;  // rounds a wave may wait for a slot before it gives the frame up (a
                                                 // column of 64 samples of ten bounces ends within some 1500)
-__host__ __device__ constexpr size_t ring_bytes_per_wave(uint32_t slots)
+constexpr uint32_t kRingMetaValid = 0x80000000u;
+
+// Number of lanes below this one whose bit is set in `mask`: two instructions, and no per-lane mask to keep.
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 {
-  return slots == 0u ? 0u : sizeof(uint32_t) * (2u * 64u + kRingMaxSlots * kRingHeaderWords) + (size_t)slots * 3u * 64u * sizeof(float);
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// LDS of one wave's ring: [pending 64][meta 64][headers kRingMaxSlots x kRingHeaderWords][sums slots x kItemBatch x 3].
+// Window a lane's slot names (both forms of Lane::slot in a kernel that takes the pixel sums itself: slot * 64 +
+// column for a column from the queue; RT_SHARED_SLOT | owner lane << 16 | slot << 6 | place for a shared sample).
+__device__ __forceinline__ uint32_t ring_window_of(uint32_t lane_slot) { return (lane_slot >> 6) & 7u; }
+
+// LDS of one wave's ring: [meta 64][headers kRingMaxSlots x kRingHeaderWords][state kRingStateWords][sums slots x
+// kItemBatch x 3].  Whatever the ring needs only now and then lives in the state words, not in scalar registers (the
+// kernel has none to spare: every one more is one more spilled, and the spills cost a vector register): the queue
+// position behind the newest window's last column, the count of refused openings, and the arguments of the launch
+// that only the end of a window reads.
+constexpr uint32_t kRingStateWords = 12;
+constexpr uint32_t kRingStalls = 1, kRingPlanes = 2, kRingPixels = 4, kRingShared = 5, kRingShareDepth = 7,
+                   kRingErrors = 8;
+__host__ __device__ constexpr size_t ring_bytes_per_wave(uint32_t slots)
+{
+  return slots == 0u ? 0u : sizeof(uint32_t) * (64u + kRingMaxSlots * kRingHeaderWords + kRingStateWords) + (size_t)slots * 3u * 64u * sizeof(float);
+}
+
 struct PixelRing
 {
   uint32_t * words = nullptr;   // LDS: the wave's region (all offsets below are constants)
-  uint32_t slots = 0;
-  uint32_t head = 0;            // slot of the window being handed out
-  uint32_t stalls = 0;          // consecutive refusals of can_open
+  // One scalar: bits 0..7 the slot of the newest window (the one being handed out), 8..15 the number of unfinished
+  // windows (the slots head - open + 1 ... head, modulo the slot count), 16..23 the slot count, 24..31 log2(s_row).
+  uint32_t packed = 0;
 
-  __device__ __forceinline__ uint32_t * pending() const { return words; }
-  __device__ __forceinline__ uint32_t * meta() const { return words + 64u; }
-  __device__ __forceinline__ uint32_t * hdr() const { return words + 128u; }
-  __device__ __forceinline__ float * sums() const { return reinterpret_cast<float *>(words + 128u + kRingMaxSlots * kRingHeaderWords); }
-
-  __device__ __forceinline__ void init(unsigned char * wave_lds, uint32_t n_slots)
+  __device__ __forceinline__ uint32_t head() const { return packed & 0xFFu; }
+  __device__ __forceinline__ uint32_t open() const { return (packed >> 8) & 0xFFu; }
+  __device__ __forceinline__ uint32_t slots() const { return (packed >> 16) & 0xFFu; }
+  __device__ __forceinline__ uint32_t s_shift() const { return packed >> 24; }
+  __device__ __forceinline__ uint32_t * meta() const { return words; }
+  __device__ __forceinline__ uint32_t * hdr() const { return words + 64u; }
+  __device__ __forceinline__ uint32_t * state() const { return words + 64u + kRingMaxSlots * kRingHeaderWords; }
+  __device__ __forceinline__ float * sums() const { return reinterpret_cast<float *>(words + 64u + kRingMaxSlots * kRingHeaderWords + kRingStateWords); }
+  __device__ __forceinline__ uint32_t state_word(uint32_t k) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)state()[k]); }
+  template <class T>
+  __device__ __forceinline__ T * state_pointer(uint32_t k) const
   {
-    slots = n_slots;
+    return reinterpret_cast<T *>((unsigned long long)state()[k] | ((unsigned long long)state()[k + 1u] << 32));
+  }
+  __device__ __forceinline__ uint32_t tail() const
+  {
+    uint32_t const t = head() + 1u + slots() - open();  // in [1, 2 slots)
+    return t >= slots() ? t - slots() : t;
+  }
+
+  __device__ __forceinline__ void init(const TraceArgs & A, unsigned char * wave_lds)
+  {
     words = reinterpret_cast<uint32_t *>(wave_lds);
     uint32_t const lane = __lane_id();
-    if (lane < kRingMaxSlots * kRingHeaderWords)
-      hdr()[lane] = 0u;
-    pending()[lane] = 0u;
     meta()[lane] = 0u;
-    head = slots - 1u;
+    if (lane == 0u)
+    {
+      unsigned long long const planes = reinterpret_cast<unsigned long long>(A.planes);
+      unsigned long long const shared = reinterpret_cast<unsigned long long>(A.shared);
+      unsigned long long const errors = reinterpret_cast<unsigned long long>(A.ring_errors);
+      state()[kRingStalls] = 0u;
+      state()[kRingPlanes] = (uint32_t)planes;
+      state()[kRingPlanes + 1u] = (uint32_t)(planes >> 32);
+      state()[kRingPixels] = A.n_pixels;
+      state()[kRingShared] = (uint32_t)shared;
+      state()[kRingShared + 1u] = (uint32_t)(shared >> 32);
+      state()[kRingShareDepth] = A.share_depth;
+      state()[kRingErrors] = (uint32_t)errors;
+      state()[kRingErrors + 1u] = (uint32_t)(errors >> 32);
+    }
+    packed = (A.ring_slots - 1u) | (A.ring_slots << 16) | (A.s_shift << 24);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __device__ __forceinline__ uint32_t next_head() const { return head + 1u == slots ? 0u : head + 1u; }
-  // May the next window be opened?  Not while the slot it would take still waits for columns.
-  __device__ __forceinline__ bool can_open() const
+  __device__ __forceinline__ void raise_error() const { atomicAdd(state_pointer<unsigned long long>(kRingErrors), 1ull); }
+  // May the next window be opened?  Not while every slot holds an unfinished window.
+  __device__ __forceinline__ bool can_open() const { return open() < slots(); }
+  // Counts a refused opening; true when the wave has been refused kRingStallLimit times in a row.
+  __device__ __forceinline__ bool refused()
   {
-    return __builtin_amdgcn_readfirstlane((int)hdr()[next_head() * kRingHeaderWords]) == 0;
+    uint32_t const n = state_word(kRingStalls) + 1u;
+    if (lane_here() == 0u)
+      state()[kRingStalls] = n;
+    return n >= kRingStallLimit;
   }
   // The window of `valid` columns whose first item is `first_item` takes the next slot.
-  __device__ __forceinline__ void opened(const TraceArgs & A, uint32_t valid, uint32_t first_item)
+  __device__ __forceinline__ void opened(uint32_t valid, uint32_t first_item)
   {
-    head = next_head();
-    if (__lane_id() == 0)
+    uint32_t const h = head() + 1u == slots() ? 0u : head() + 1u;
+    packed = ((packed & 0xFFFFFF00u) | h) + 0x100u;
+    if (lane_here() == 0u)
     {
-      hdr()[head * kRingHeaderWords + 0u] = valid;
-      hdr()[head * kRingHeaderWords + 1u] = 0u;
-      hdr()[head * kRingHeaderWords + 2u] = first_item >> A.s_shift;
+      hdr()[h * kRingHeaderWords + 0u] = valid;
+      hdr()[h * kRingHeaderWords + 1u] = first_item >> s_shift();
+      state()[kRingStalls] = 0u;
     }
+  }
+
+  // The oldest window is complete: shared samples join their columns, the pixels are summed and written, the slot
+  // is free.  `end_of_queue`: samples may have been shared (only then).  s_row, slice_count: TraceArgs'.
+  __device__ __forceinline__ void complete_tail(uint32_t s_row, uint32_t slice_count, uint32_t lane, bool end_of_queue)
+  {
+    uint32_t const w = tail();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-
-  // Completes the sum of the column lane `owner` of this wave owns: its own part, then the shared colours in
-  // increasing sy (rt_core.h fold_split does the same after the kernel).  Returns the column's place in the ring.
-  __device__ __forceinline__ uint32_t fold(const TraceArgs & A, uint32_t owner, uint32_t wave_first) const
-  {
-    uint32_t const m = meta()[owner];
-    uint32_t const wc = m & 0xFFFFu;
-    float * const s = sums() + 3u * wc;
-    f3 sum = mk3(s[0], s[1], s[2]);
-    size_t const base = (size_t)(wave_first + owner) * A.share_depth;
-    for (uint32_t sy = m >> 16; sy < A.s_row; sy += A.slice_count)
+    if (end_of_queue)
     {
-      // written by other lanes of this wave: read past the vector cache, which may hold an older copy of the line
-      const float * const v = A.shared + 3u * (base + (A.s_row - 1u - sy));
-      float const x = __hip_atomic_load(v + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float const y = __hip_atomic_load(v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float const z = __hip_atomic_load(v + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sum = sum + mk3(x, y, z);
-    }
-    s[0] = sum.x;
-    s[1] = sum.y;
-    s[2] = sum.z;
-    return wc;
-  }
-
-  // Called by the whole wave; lanes with `finishing` have a complete column or shared sample in L.sum.
-  __device__ __forceinline__ void finish(const TraceArgs & A, const Lane & L, bool finishing)
-  {
-    uint32_t const lane = __lane_id();
-    uint32_t const wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
-    uint32_t done_col = RT_INVALID;  // place in the ring of a column this lane completed
-    if (finishing)
-    {
-      if ((L.slot & RT_SHARED_SLOT) == 0u)
+      // Lane l looks after the column lane l owned: its own part, then the shared colours in increasing sy
+      // (rt_core.h fold_split does the same after a kernel that leaves column sums).
+      uint32_t const m = meta()[lane];
+      if ((m & kRingMetaValid) != 0u && ring_window_of(m) == w)
       {
-        uint32_t const wc = L.slot;
+        uint32_t const wc = m & 0x1FFu;
         float * const s = sums() + 3u * wc;
-        s[0] = L.sum.x;
-        s[1] = L.sum.y;
-        s[2] = L.sum.z;
-        if (L.sy_end < A.s_row)
+        f3 sum = mk3(s[0], s[1], s[2]);
+        uint32_t const wave_first = blockIdx.x * blockDim.x + wave_in_block() * 64u;
+        size_t const base = (size_t)(wave_first + lane) * state()[kRingShareDepth];
+        const float * const shared = state_pointer<const float>(kRingShared);
+        for (uint32_t sy = (m >> 16) & 0x7FFFu; sy < s_row; sy += slice_count)
         {
-          // samples of this column were handed to other lanes: this is the owner's part
-          meta()[lane] = wc | (L.sy_end << 16);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          if (atomicSub(&pending()[lane], 1u) == 1u)
-            done_col = fold(A, lane, wave_first);
+          // written by other lanes of this wave: read past the vector cache, which may hold an older copy of the line
+          const float * const v = shared + 3u * (base + (s_row - 1u - sy));
+          float const x = __hip_atomic_load(v + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          float const y = __hip_atomic_load(v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          float const z = __hip_atomic_load(v + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sum = sum + mk3(x, y, z);
         }
-        else
-          done_col = wc;
+        s[0] = sum.x;
+        s[1] = sum.y;
+        s[2] = sum.z;
+        meta()[lane] = 0u;
       }
-      else
-      {
-        uint32_t const owner = (L.slot >> 16) & 63u;
-        uint32_t const place = L.slot & 0xFFFFu;
-        if (place < A.share_depth)
-          store3(A.shared + 3u * ((size_t)(wave_first + owner) * A.share_depth + place), L.sum);
-        else
-          atomicAdd(A.ring_errors, 1ull);  // (never: the places of a region are share_depth)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the colour is in memory before it is counted
-        if (atomicSub(&pending()[owner], 1u) == 1u)
-          done_col = fold(A, owner, wave_first);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t full = RT_INVALID;  // a window this lane's column completed
-    if (done_col != RT_INVALID)
-    {
-      uint32_t const w = done_col >> 6;
-      uint32_t const before = atomicAdd(&hdr()[w * kRingHeaderWords + 1u], 1u);
-      if (before + 1u == hdr()[w * kRingHeaderWords + 0u])
-        full = w;
-    }
-    unsigned long long windows = __ballot(full != RT_INVALID);
-    while (windows != 0ull)
-    {
-      uint32_t const src = (uint32_t)__builtin_ctzll(windows);
-      windows &= windows - 1ull;
-      uint32_t const w = (uint32_t)__builtin_amdgcn_readlane((int)full, (int)src);
-      uint32_t const valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr()[w * kRingHeaderWords + 0u]);
-      uint32_t const first_pixel = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr()[w * kRingHeaderWords + 2u]);
-      if (lane < (valid >> A.s_shift))
-      {
-        // the accumulate pass of this pixel: 0 + column 0 + column 1 + ... as colsum_kernel adds them
-        const float * c = sums() + 3u * (w * 64u + (lane << A.s_shift));
-        float r = 0.0f, g = 0.0f, b = 0.0f;
-        for (uint32_t i = 0; i < A.s_row; ++i, c += 3)
-        {
-          r += c[0];
-          g += c[1];
-          b += c[2];
-        }
-        size_t const px = (size_t)first_pixel + lane;
-        if (px < A.n_pixels)
-        {
-          A.planes[px] = r;
-          A.planes[(size_t)A.n_pixels + px] = g;
-          A.planes[2u * (size_t)A.n_pixels + px] = b;
-        }
-        else
-          atomicAdd(A.ring_errors, 1ull);  // (never: a window's pixels are pixels of the frame)
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0u)
-        hdr()[w * kRingHeaderWords + 0u] = 0u;  // the slot is free
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    uint32_t const valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr()[w * kRingHeaderWords + 0u]);
+    uint32_t const first_pixel = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr()[w * kRingHeaderWords + 1u]);
+    if (lane < (valid >> s_shift()))
+    {
+      // the accumulate pass of this pixel: 0 + column 0 + column 1 + ... as colsum_kernel adds them
+      const float * c = sums() + 3u * (w * 64u + (lane << s_shift()));
+      float r = 0.0f, g = 0.0f, b = 0.0f;
+      for (uint32_t i = 0; i < s_row; ++i, c += 3)
+      {
+        r += c[0];
+        g += c[1];
+        b += c[2];
+      }
+      size_t const n_pixels = state()[kRingPixels];
+      float * const planes = state_pointer<float>(kRingPlanes);
+      size_t const px = (size_t)first_pixel + lane;
+      if (px < n_pixels)
+      {
+        planes[px] = r;
+        planes[n_pixels + px] = g;
+        planes[2u * n_pixels + px] = b;
+      }
+      else
+        raise_error();  // (never: a window's pixels are pixels of the frame)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    packed -= 0x100u;
+  }
+
+  // Lanes with `finishing` have a complete column or shared sample in L.sum: it goes to its place in the ring (a
+  // shared sample's colour to memory).  No window is finished here: that happens when the wave opens its next
+  // window (retire) and when it has no more work (drain), not in every round.
+  __device__ __forceinline__ void park(const TraceArgs & A, const Lane & L, bool finishing) const
+  {
+    if (!finishing)
+      return;
+    if ((L.slot & RT_SHARED_SLOT) == 0u)
+    {
+      float * const s = sums() + 3u * (L.slot & 0x1FFu);
+      s[0] = L.sum.x;
+      s[1] = L.sum.y;
+      s[2] = L.sum.z;
+      if (L.sy_end < A.s_row)  // samples of this column were handed to other lanes: this is the owner's part
+        meta()[lane_here()] = kRingMetaValid | (L.sy_end << 16) | (L.slot & 0x1FFu);
+    }
+    else
+    {
+      uint32_t const owner = (L.slot >> 16) & 63u;
+      uint32_t const place = L.slot & 63u;
+      uint32_t const wave_first = blockIdx.x * blockDim.x + wave_in_block() * 64u;
+      uint32_t const depth = state()[kRingShareDepth];
+      if (place < depth)
+        store3(state_pointer<float>(kRingShared) + 3u * ((size_t)(wave_first + owner) * depth + place), L.sum);
+      else
+        raise_error();  // (never: the places of a region are share_depth)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the colour is in memory before its window is finished
+    }
+  }
+
+  // Finishes the oldest windows that no lane holds a column (or a shared sample) of any more.  Called when every
+  // open window has been handed out completely: when the wave is about to open the next one.  holds, lane_slot:
+  // whether the lane holds a column or shared sample, and its Lane::slot.
+  __device__ __forceinline__ void retire(const TraceArgs & A, bool holds, uint32_t lane_slot, bool end_of_queue)
+  {
+    while (open() != 0u && __ballot(holds && ring_window_of(lane_slot) == tail()) == 0ull)
+      complete_tail(A.s_row, A.slice_count, lane_here(), end_of_queue);
+  }
+
+  // The wave has no more work: every column it was handed is done, so every window still open is complete.
+  __device__ __forceinline__ void drain(const TraceArgs & A)
+  {
+    while (open() != 0u)
+      complete_tail(A.s_row, A.slice_count, lane_here(), true);
   }
 };
 
@@ -333,7 +399,7 @@ struct ItemPool
       }
       last_size = size;
       uint32_t base = 0;
-      if (__lane_id() == 0)
+      if (lane_here() == 0u)
       {
         // A cancelled job stops at a reservation: the wave is sent past the end of the queue.  The flag may
         // live in host memory, a slow read, so only every kCancelPoll-th reservation looks at it.
@@ -361,32 +427,36 @@ struct ItemPool
   // kRingStallLimit times in a row -- which no frame does: a busy slot means a lane of this wave is still tracing
   // one of its columns -- gives up: it reports the queue used up, so that the launch ends, and raises
   // TraceArgs::ring_errors.
+  // L, info: the lane's state, and what the call that asks for the window has handed the lane so far (a column
+  // handed out a moment ago is not in L yet).
   template <bool kFused>
-  __device__ __forceinline__ bool open(const TraceArgs & A, PixelRing & ring)
+  __device__ __forceinline__ bool open(const TraceArgs & A, PixelRing & ring, const Lane & L, const ItemInfo & info)
   {
+    if constexpr (kFused)
+    {
+      bool const just_got = info.pos != RT_INVALID;
+      ring.retire(A, just_got || (L.alive && !L.need_item), just_got ? info.slot : L.slot, exhausted);
+    }
     if (kFused && !ring.can_open())
     {
-      ring.stalls += 1u;
-      if (ring.stalls < kRingStallLimit)
+      if (!ring.refused())
         return false;
-      if (__lane_id() == 0)
-        atomicAdd(A.ring_errors, 1ull);
+      if (lane_here() == 0u)
+        ring.raise_error();
       exhausted = true;
       next = end;
       return true;
     }
-    ring.stalls = 0u;
     refill(A);
     if (kFused && next < A.queue_items)
-      ring.opened(A, min(kItemBatch, A.queue_items - next), next + delta);
+      ring.opened(min(kItemBatch, A.queue_items - next), next + delta);
     return true;
   }
 
   // Hands the next queue positions to the lanes that need one: info.pos (the item) and info.slot.
   template <bool kFused>
-  __device__ __forceinline__ void fetch(const TraceArgs & A, PixelRing & ring, bool need, ItemInfo & info)
+  __device__ __forceinline__ void fetch(const TraceArgs & A, PixelRing & ring, const Lane & L, bool need, ItemInfo & info)
   {
-    uint32_t const lane = __lane_id();
     for (;;)
     {
       unsigned long long const mask = __ballot(need);
@@ -396,7 +466,7 @@ struct ItemPool
       {
         if (exhausted)
           break;
-        if (!open<kFused>(A, ring))
+        if (!open<kFused>(A, ring, L, info))
         {
           info.stalled = true;
           break;
@@ -406,13 +476,13 @@ struct ItemPool
       }
       uint32_t const avail = end - next;
       uint32_t const wanted = (uint32_t)__popcll(mask);
-      uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      uint32_t const rank = lanes_below(mask);
       if (need && rank < avail)
       {
         if (next + rank < A.queue_items)
         {
           info.pos = next + rank + delta;
-          info.slot = kFused ? ring.head * kItemBatch + (next + rank - (end - kItemBatch)) : info.pos;
+          info.slot = kFused ? ring.head() * kItemBatch + (next + rank - (end - kItemBatch)) : info.pos;
         }
         need = false;
       }
@@ -435,7 +505,7 @@ __device__ __forceinline__ float lane_value(float v, uint32_t lane)
 // owner's column.  Everything here is wave-wide and needs no memory traffic: the owner's ray set-up travels
 // through lane reads.  The region of a lane is its index in the launch, so no two owners share one.
 template <bool kFused>
-__device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L, const PixelRing & ring)
+__device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L)
 {
   if (A.share_depth == 0u)
     return;
@@ -446,12 +516,12 @@ __device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L, con
   unsigned long long donors = __ballot(spare != 0u);
   if (donors == 0ull)
     return;
-  uint32_t const lane = __lane_id();
+  uint32_t const lane = lane_here();
   uint32_t const n_idle = (uint32_t)__popcll(idle);
   uint32_t const per = max(1u, n_idle / (uint32_t)__popcll(donors));
-  uint32_t const my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+  uint32_t const my_rank = lanes_below(idle);
   bool const was_idle = !L.alive;
-  uint32_t const wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
+  uint32_t const wave_first = blockIdx.x * blockDim.x + wave_in_block() * 64u;
   uint32_t taken = 0u;
   while (donors != 0ull && taken < n_idle)
   {
@@ -459,31 +529,22 @@ __device__ __forceinline__ void share_samples(const TraceArgs & A, Lane & L, con
     donors &= donors - 1ull;
     uint32_t const give = min(min(lane_value(spare, d), per), n_idle - taken);
     uint32_t const d_end = lane_value(L.sy_end, d), d_sy = lane_value(L.sy, d);
-    uint32_t const d_pixel = lane_value(L.pixel, d), d_sx = lane_value(L.sx, d);
+    uint32_t const d_slot = kFused ? lane_value(L.slot, d) : 0u;
+    uint32_t const d_pixel = lane_value(L.pixel, d), d_sx = kFused ? (d_slot & (A.s_row - 1u)) : lane_value(L.sx, d);
     uint32_t const d_cm0 = lane_value(L.cm0, d), d_cm1 = lane_value(L.cm1, d);
     float const d_sdx = lane_value(L.sdx, d), d_dyp = lane_value(L.dyp, d);
     if (lane == d)
     {
       L.sy_end = spare_sample_sy(A, d_sy, d_end, give - 1u);  // the owner keeps what lies below
-      // pixel sums in the kernel: what the column still waits for -- these samples and, counted with the first
-      // ones handed out, the owner's own part
-      if constexpr (kFused)
-        ring.pending()[d] += give + (d_end == A.s_row ? 1u : 0u);
     }
     if (was_idle && my_rank >= taken && my_rank < taken + give)
     {
       uint32_t const sy = spare_sample_sy(A, d_sy, d_end, my_rank - taken);
       take_shared_sample(A, L, (wave_first + d) * A.share_depth, d_pixel, d_sx, d_sdx, d_dyp, d_cm0, d_cm1, sy);
-      if constexpr (kFused)
-        L.slot = RT_SHARED_SLOT | (d << 16) | (A.s_row - 1u - sy);  // the owner's lane and the colour's place in its region
+      if constexpr (kFused)  // the owner's lane, sx and window of its column, the colour's place in the owner's region
+        L.slot = RT_SHARED_SLOT | (d << 16) | (d_sx << 9) | (ring_window_of(d_slot) << 6) | (A.s_row - 1u - sy);
     }
     taken += give;
-  }
-  if constexpr (kFused)
-  {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -523,12 +584,21 @@ struct WaveEnv
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
-  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L, ring); }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  // (kFused: a window holds whole pixels and starts at one, so a column's place in its window gives sx; a shared
+  // sample carries the owner's sx in bits 9..14 of its slot)
+  __device__ __forceinline__ uint32_t column_sx(const Lane & L) const
+  {
+    if constexpr (kFused)
+      return (L.slot & RT_SHARED_SLOT) != 0u ? ((L.slot >> 9) & 63u) : (L.slot & (A.s_row - 1u));
+    else
+      return L.sx;
+  }
   __device__ __forceinline__ void finish_columns(Lane & L, bool finishing)
   {
     if constexpr (kFused)
-      ring.finish(A, L, finishing);
+      ring.park(A, L, finishing);
     else if (finishing)
       store_column(A, L, *this);
   }
@@ -546,7 +616,7 @@ struct WaveEnv
   // With column masks the wave prepares a whole window when it opens one: lane l sets up the column at queue
   // position base + l (ray set-up and candidate masks, one filter pass per column instead of one per sample)
   // and parks it in the wave's LDS table, from where the lanes pick their columns up.
-  __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
+  __device__ __forceinline__ void fetch_item(const Lane & L, bool need, ItemInfo & info)
   {
     info.pos = RT_INVALID;
     info.slot = RT_INVALID;
@@ -555,10 +625,10 @@ struct WaveEnv
     info.filter_tests = 0u;
     if (A.column_masks == 0u)
     {
-      pool.template fetch<kFused>(A, ring, need, info);
+      pool.template fetch<kFused>(A, ring, L, need, info);
       return;
     }
-    uint32_t const lane = __lane_id();
+    uint32_t const lane = lane_here();
     for (;;)
     {
       unsigned long long const mask = __ballot(need);
@@ -568,7 +638,7 @@ struct WaveEnv
       {
         if (pool.exhausted)
           break;
-        if (!pool.template open<kFused>(A, ring))
+        if (!pool.template open<kFused>(A, ring, L, info))
         {
           info.stalled = true;
           break;
@@ -580,16 +650,15 @@ struct WaveEnv
         ColumnEntry e;
         e.pixel = RT_INVALID;
         if (pool.next + lane < A.queue_items)
-        {
           e = prepare_column(A, cam, pool.next + lane + pool.delta);
-          info.filter_tests += 1u;
-        }
+        if (pool.next < A.queue_items)
+          info.filter_tests += min(kItemBatch, A.queue_items - pool.next);
         batch[lane] = e;
         __builtin_amdgcn_wave_barrier();
       }
       uint32_t const avail = pool.end - pool.next;
       uint32_t const wanted = (uint32_t)__popcll(mask);
-      uint32_t const rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      uint32_t const rank = lanes_below(mask);
       if (need && rank < avail)
       {
         uint32_t const column = pool.next + rank - (pool.end - kItemBatch);
@@ -597,7 +666,7 @@ struct WaveEnv
         if (e.pixel != RT_INVALID)
         {
           info.pos = pool.next + rank + pool.delta;
-          info.slot = kFused ? ring.head * kItemBatch + column : info.pos;
+          info.slot = kFused ? ring.head() * kItemBatch + column : info.pos;
           info.prepared = true;
           info.sdx = e.sdx;
           info.dyp = e.dyp;
@@ -637,23 +706,32 @@ struct BlockEnv
   __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
-  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L, ring); }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  // (kFused: a window holds whole pixels and starts at one, so a column's place in its window gives sx; a shared
+  // sample carries the owner's sx in bits 9..14 of its slot)
+  __device__ __forceinline__ uint32_t column_sx(const Lane & L) const
+  {
+    if constexpr (kFused)
+      return (L.slot & RT_SHARED_SLOT) != 0u ? ((L.slot >> 9) & 63u) : (L.slot & (A.s_row - 1u));
+    else
+      return L.sx;
+  }
   __device__ __forceinline__ void finish_columns(Lane & L, bool finishing)
   {
     if constexpr (kFused)
-      ring.finish(A, L, finishing);
+      ring.park(A, L, finishing);
     else if (finishing)
       store_column(A, L, *this);
   }
-  __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
+  __device__ __forceinline__ void fetch_item(const Lane & L, bool need, ItemInfo & info)
   {
     info.pos = RT_INVALID;
     info.slot = RT_INVALID;
     info.stalled = false;
     info.prepared = false;
     info.filter_tests = 0u;
-    pool.template fetch<kFused>(A, ring, need, info);
+    pool.template fetch<kFused>(A, ring, L, need, info);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -697,23 +775,32 @@ struct GridEnv
   __device__ __forceinline__ int count(bool p) const { return (int)__popcll(__ballot(p)); }
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
-  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L, ring); }
+  __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L); }
   __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  // (kFused: a window holds whole pixels and starts at one, so a column's place in its window gives sx; a shared
+  // sample carries the owner's sx in bits 9..14 of its slot)
+  __device__ __forceinline__ uint32_t column_sx(const Lane & L) const
+  {
+    if constexpr (kFused)
+      return (L.slot & RT_SHARED_SLOT) != 0u ? ((L.slot >> 9) & 63u) : (L.slot & (A.s_row - 1u));
+    else
+      return L.sx;
+  }
   __device__ __forceinline__ void finish_columns(Lane & L, bool finishing)
   {
     if constexpr (kFused)
-      ring.finish(A, L, finishing);
+      ring.park(A, L, finishing);
     else if (finishing)
       store_column(A, L, *this);
   }
-  __device__ __forceinline__ void fetch_item(bool need, ItemInfo & info)
+  __device__ __forceinline__ void fetch_item(const Lane & L, bool need, ItemInfo & info)
   {
     info.pos = RT_INVALID;
     info.slot = RT_INVALID;
     info.stalled = false;
     info.prepared = false;
     info.filter_tests = 0u;
-    pool.template fetch<kFused>(A, ring, need, info);
+    pool.template fetch<kFused>(A, ring, L, need, info);
   }
   __device__ __forceinline__ f4 sphere(int i) const { return A.spheres[i]; }
   __device__ __forceinline__ uint32_t sphere_material(int i) const { return A.sphere_mat[i]; }
@@ -747,12 +834,12 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
   unsigned long long const c1 = wave_sum(cnt.queries);
   unsigned long long const c2 = wave_sum(cnt.hits);
   unsigned long long const c3 = wave_sum(cnt.shaded);
-  unsigned long long const c4 = wave_sum(cnt.filter_tests) * A.n_spheres;
+  unsigned long long const c4 = (wave_sum(cnt.filter_tests) + cnt.prepared) * A.n_spheres;
   unsigned long long const c8 = wave_sum(cnt.cone_tests);
   unsigned long long const c5 = wave_sum(cnt.exact_tests);
   unsigned long long const c6 = wave_sum(cnt.trips);
   unsigned long long const c7 = wave_sum(cnt.rounds);
-  if (A.stats != nullptr && __lane_id() == 0)
+  if (A.stats != nullptr && lane_here() == 0u)
   {
     atomicAdd(&A.stats[0], c0);
     atomicAdd(&A.stats[1], c1);
@@ -766,7 +853,7 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
   }
 #if defined(RT_PROFILE_REGIONS)
   RT_REGION(cnt, 4);
-  if (__lane_id() == 0)
+  if (lane_here() == 0u)
     for (int k = 0; k < RT_REGION_COUNT; ++k)
       atomicAdd(&g_region_ticks[k], cnt.region[k]);
 #endif
@@ -799,9 +886,11 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
     float * const cone = reinterpret_cast<float *>(sph + kTile);
     BlockEnv<kLibMath, kFused> env{A, sph, cone, kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool(), PixelRing()};
     if constexpr (kFused)
-      env.ring.init(reinterpret_cast<unsigned char *>(cone + kTile) + (threadIdx.x / 64u) * ring_bytes_per_wave(A.ring_slots), A.ring_slots);
+      env.ring.init(A, reinterpret_cast<unsigned char *>(cone + kTile) + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
     __syncthreads();
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    if constexpr (kFused)
+      env.ring.drain(A);
   }
   else
   {
@@ -831,11 +920,12 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
-    WaveEnv<kLibMath, kFused> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + (threadIdx.x / 64u) * kItemBatch, ItemPool(), PixelRing()};
+    WaveEnv<kLibMath, kFused> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + wave_in_block() * kItemBatch, ItemPool(), PixelRing()};
     if constexpr (kFused)
-      env.ring.init(reinterpret_cast<unsigned char *>(batch + (kBlock / 64u) * kItemBatch) + (threadIdx.x / 64u) * ring_bytes_per_wave(A.ring_slots),
-                    A.ring_slots);
+      env.ring.init(A, reinterpret_cast<unsigned char *>(batch + (kBlock / 64u) * kItemBatch) + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+    if constexpr (kFused)
+      env.ring.drain(A);
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
 #endif
@@ -861,8 +951,10 @@ __global__ __launch_bounds__(kBlock, kForward ? kWavesPerSimdForward : kWavesPer
 #endif
   GridEnv<kLibMath, kFused> env{A, jitter, ItemPool(), PixelRing()};
   if constexpr (kFused)
-    env.ring.init(reinterpret_cast<unsigned char *>(jitter + RT_JITTER_FLOATS) + (threadIdx.x / 64u) * ring_bytes_per_wave(A.ring_slots), A.ring_slots);
+    env.ring.init(A, reinterpret_cast<unsigned char *>(jitter + RT_JITTER_FLOATS) + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
   trace_loop<kForward, true, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
+  if constexpr (kFused)
+    env.ring.drain(A);
   flush_counters(A, cnt);
 }
 
@@ -1308,12 +1400,11 @@ bool needs_library_math(const rt_hip_scene * sc, const rt_hip_camera * camera)
 // blocks move in step and the samples cost a hundred times as much.
 constexpr unsigned long long kSamplesPerLane = 36;
 // Blocks per compute unit of the trace kernel for this scene, and the ring it can afford (rt_hip_scene::Occupancy).
-// RT_HIP_NO_FUSE (any value): no ring, the column sums go to memory and the accumulate pass adds them, for
-// comparisons; RT_HIP_RING_SLOTS=n: at most n slots.
+// RT_HIP_RING_SLOTS=n: at most n slots (experiments).
 rt_hip_scene::Occupancy launch_shape(const rt_hip_scene * sc, uint32_t flags, bool library_math)
 {
   size_t const lds = lds_bytes(sc, flags, 0u);
-  uint32_t most = std::getenv("RT_HIP_NO_FUSE") ? 0u : kRingMaxSlots;
+  uint32_t most = kRingMaxSlots;
   if (const char * v = std::getenv("RT_HIP_RING_SLOTS"))
     most = std::min<uint32_t>(most, (uint32_t)std::strtoul(v, nullptr, 10));
   std::lock_guard<std::mutex> lock(sc->occupancy_mutex);
@@ -1348,11 +1439,16 @@ rt_hip_scene::Occupancy launch_shape(const rt_hip_scene * sc, uint32_t flags, bo
   return shape;
 }
 
-// The pixel sums of a frame are taken inside the trace kernel when a window of the work queue holds whole pixels
-// (samples_in_row divides kItemBatch) and the scene's launch has room for a ring.
+// The pixel sums of a frame are taken inside the trace kernel when the caller asks for it (RT_HIP_FLAG_KERNEL_SUMS; or
+// RT_HIP_KERNEL_SUMS in the environment, any value, for comparisons), a window of the work queue holds whole pixels
+// (samples_in_row divides kItemBatch) and the scene's launch has room for a ring.  Otherwise the kernel leaves column
+// sums and the accumulate pass adds them: the faster of the two on this part (the kernels with the ring run 3-5 %
+// longer, more than the pass they save), but 12 bytes of workspace per sub-sample column of the frame.
 uint32_t frame_ring_slots(const rt_hip_scene * sc, const rt_hip_trace_params * p, bool library_math)
 {
   uint32_t const s = p->samples_in_row;
+  if ((p->flags & RT_HIP_FLAG_KERNEL_SUMS) == 0u && std::getenv("RT_HIP_KERNEL_SUMS") == nullptr)
+    return 0u;
   if (s == 0u || s > kItemBatch || (kItemBatch % s) != 0u)
     return 0u;
   return launch_shape(sc, p->flags, library_math).ring_slots;
@@ -2282,15 +2378,25 @@ int rt_hip_trace_device_static(const rt_hip_scene * scene, const rt_hip_camera *
     return fail(RT_HIP_ERR_DEVICE, "the static scratch array has no address on this device");
   if (scene->n_padded > kStaticMaxSpheres)
     return fail(RT_HIP_ERR_INVALID, "rt_hip_trace_device_static takes scenes of at most 16384 spheres");
-  // A frame whose pixel sums the kernel takes itself keeps no column sums: only the others are limited by the array.
-  bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
+  // A frame whose pixel sums the kernel takes itself keeps no column sums, so it is not limited by the array: frames
+  // whose column sums do not fit are traced that way where they can be.
+  rt_hip_trace_params with_sums = *params;
+  bool fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
   if (!fused && partial_bytes(params) > kStaticPartialBytes)
   {
-    char msg[320];
+    with_sums.flags |= RT_HIP_FLAG_KERNEL_SUMS;
+    fused = frame_ring_slots(scene, &with_sums, needs_library_math(scene, camera)) != 0u;
+    if (fused)
+      params = &with_sums;
+  }
+  if (!fused && partial_bytes(params) > kStaticPartialBytes)
+  {
+    char msg[400];
     std::snprintf(msg, sizeof(msg),
                   "rt_hip_trace_device_static: width * height * samples_in_row is %llu, the limit is %llu (12 bytes per "
-                  "sub-sample column in a 64 MiB static array) for frames whose samples_in_row is not 1, 2, 4, 8, 16, 32 or "
-                  "64; rt_hip_trace_device has no such limit",
+                  "sub-sample column in a 64 MiB static array) for frames whose pixel sums the trace kernel cannot take "
+                  "itself (samples_in_row other than 1, 2, 4, 8, 16, 32, 64, or a scene that needs path stacks or the "
+                  "general arithmetic); rt_hip_trace_device has no such limit",
                   frame_items(params), (unsigned long long)(kStaticPartialBytes / (3u * sizeof(float))));
     return fail(RT_HIP_ERR_INVALID, msg);
   }
@@ -2459,7 +2565,7 @@ __global__ __launch_bounds__(256) void exact_math_check_kernel(unsigned long lon
     unsigned long long v = bad[c];
     for (int off = 32; off > 0; off >>= 1)
       v += __shfl_down(v, off);
-    if (__lane_id() == 0 && v != 0ull)
+    if (lane_here() == 0u && v != 0ull)
       atomicAdd(&out[c], v);
   }
 }

@@ -13,6 +13,7 @@ FLAG_GRID = 2
 FLAG_PIPELINED = 4
 FLAG_LEAVE_ROOM = 8
 FLAG_PIXEL_RUNS = 16
+FLAG_KERNEL_SUMS = 32
 
 RT_HIP_OK = 0
 RT_HIP_ERR_NOT_READY = 3

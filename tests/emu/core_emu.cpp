@@ -63,12 +63,13 @@ struct HostEnv
   bool any(bool p) { return p; }
   int count(bool p) { return p ? 1 : 0; }
   bool any_wave(bool p) { return p; }
+  uint32_t column_sx(const rtc::Lane & L) const { return L.sx; }
   void finish_columns(rtc::Lane & L, bool finishing)
   {
     if (finishing)
       rtc::store_column(A, L, *this);
   }
-  void fetch_item(bool need, rtc::ItemInfo & info)
+  void fetch_item(const rtc::Lane &, bool need, rtc::ItemInfo & info)
   {
     info.pos = rtc::RT_INVALID;
     info.stalled = false;
@@ -280,7 +281,7 @@ extern "C" int emu_render_mode(const float * centers_radii, const uint32_t * mat
     stats6[1] = cnt.queries;
     stats6[2] = cnt.hits;
     stats6[3] = cnt.shaded;
-    stats6[4] = (unsigned long long)cnt.filter_tests * n;
+    stats6[4] = ((unsigned long long)cnt.filter_tests + cnt.prepared) * n;
     stats6[5] = cnt.exact_tests;
   }
   return 0;

@@ -1,8 +1,8 @@
-"""Pixel sums taken inside the trace kernel against the column sums + accumulate pass (RT_HIP_NO_FUSE): the planes of
-rt_hip_trace_device must be identical bit for bit, counters included, on whole frames, slices by samples and by runs
+"""Pixel sums taken inside the trace kernel (RT_HIP_FLAG_KERNEL_SUMS) against the column sums + accumulate pass: the
+planes of rt_hip_trace_device must be identical bit for bit, counters included, on whole frames, slices by samples and by runs
 of pixels, resident, tiled and grid scenes; then the two are timed (trace kernel alone, and the whole call).
 
-python tools/fuse_check.py [quick]
+python tools/fuse_check.py [quick | time]
 Environment: RT_HIP_RING_SLOTS=n caps the windows a wave may keep unfinished (default: what fits, at most 8).
 """
 import os
@@ -16,21 +16,24 @@ import torch  # noqa: E402
 from rt_amd import ffi, sharding  # noqa: E402
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+timing_only = len(sys.argv) > 1 and sys.argv[1] == "time"
 r = ffi.HipRenderer(0)
 stream = torch.cuda.current_stream().cuda_stream
 
 
+def with_sums(p, fused):
+    q = type(p).from_buffer_copy(p)
+    q.flags = (q.flags | ffi.FLAG_KERNEL_SUMS) if fused else (q.flags & ~ffi.FLAG_KERNEL_SUMS)
+    return q
+
+
 def planes_of(scene, p, fused):
-    if fused:
-        os.environ.pop("RT_HIP_NO_FUSE", None)
-    else:
-        os.environ["RT_HIP_NO_FUSE"] = "1"
+    p = with_sums(p, fused)
     n = p.width * p.height
     planes = torch.full((3 * n,), -7.0, dtype=torch.float32, device="cuda")
     stats = torch.zeros(16, dtype=torch.int64, device="cuda")
     r.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
     torch.cuda.synchronize()
-    os.environ.pop("RT_HIP_NO_FUSE", None)
     return planes, stats[:11].cpu().tolist()
 
 
@@ -51,6 +54,8 @@ cases = [
 ]
 if quick:
     cases = cases[:6]
+if timing_only:
+    cases = []
 bad = 0
 for name, demo, spheres, fr, sl in cases:
     scene = ffi.Scene.demo(demo, 1, spheres)
@@ -78,21 +83,17 @@ if not quick:
         n = p.width * p.height
         planes = torch.empty(3 * n, dtype=torch.float32, device="cuda")
         for fused in (True, False, True, False):
-            if fused:
-                os.environ.pop("RT_HIP_NO_FUSE", None)
-            else:
-                os.environ["RT_HIP_NO_FUSE"] = "1"
-            kernel_ms, _ = r.time_trace_kernel(scene, p, 5)
+            q = with_sums(p, fused)
+            kernel_ms, _ = r.time_trace_kernel(scene, q, 5)
             for _ in range(3):
-                r.trace_device(scene, p, planes.data_ptr(), None, stream)
+                r.trace_device(scene, q, planes.data_ptr(), None, stream)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
-                r.trace_device(scene, p, planes.data_ptr(), None, stream)
+                r.trace_device(scene, q, planes.data_ptr(), None, stream)
             torch.cuda.synchronize()
             call_ms = (time.perf_counter() - t0) / 10 * 1e3
             print("%-40s %-8s trace kernel %.3f ms, call %.3f ms" % (name, "fused" if fused else "unfused", kernel_ms, call_ms), flush=True)
-        os.environ.pop("RT_HIP_NO_FUSE", None)
 r.close()
 print("FAILED: %d" % bad if bad else "all identical")
 sys.exit(1 if bad else 0)

@@ -3,7 +3,8 @@ of the headline frame, against 1/G of the whole frame.  Leaves out the RCCL redu
 
 python tools/slice_timing.py [width height samples_in_row [slice counts [demo [spheres]]]]
 Environment: RT_SLICE_BY=samples for slices by samples (default: by runs of 64 pixels, as bench.py shards),
-RT_LANES=n for n frames in flight in the second measurement (default 2), RT_AMD_LIB_DIR=dir for another build of
+RT_LANES=n for n frames in flight in the second measurement (default 2), RT_LEAVE_ROOM=1 for launches that leave 64
+block slots free (what bench.py asks for on several GPUs, so that the reduce finds compute units), RT_AMD_LIB_DIR=dir for another build of
 the libraries.
 """
 import os
@@ -33,7 +34,7 @@ base = None
 for g in ([int(v) for v in sys.argv[4].split(",")] if len(sys.argv) >= 5 else (1, 2, 4, 8)):
     ms = []
     for lanes in (1, LANES):
-        flags = ffi.FLAG_PIPELINED if lanes >= 2 else 0
+        flags = (ffi.FLAG_PIPELINED if lanes >= 2 else 0) | (ffi.FLAG_LEAVE_ROOM if os.environ.get("RT_LEAVE_ROOM") else 0)
         p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), 0, g, pixel_runs=RUNS)
         for k in range(4 if demo != 3 else 1):
             r.trace_device(scene, p, planes[k % lanes].data_ptr(), stats[k % lanes].data_ptr(), streams[k % lanes].cuda_stream)
