@@ -3,8 +3,8 @@
 
 A step is one whole frame with the scene already resident in HBM: every rank traces its slice of the
 frame (rt_hip_trace_device; runs of 64 pixels dealt out to the ranks in turn, --sample-slices for every rank's share
-of every pixel's samples), the planar sums are reduced to rank 0 over RCCL, and rank 0 runs the
-resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.  Two frames
+of every pixel's samples), the planar sums are put together on rank 0 over RCCL (a gather of each rank's own runs;
+a sum-reduce with --sample-slices), and rank 0 runs the resolve pass (rt_hip_resolve_device).  The frame is fixed, so more GPUs means strong scaling.  Two frames
 are in flight, on two streams with their own planes: while the planes of frame k are being reduced, every rank
 already traces frame k + 1, whose first waves also take over the compute units that the last waves of frame k
 leave idle (--sync-reduce runs one frame at a time instead); all K frames are reduced and resolved inside
@@ -20,12 +20,15 @@ images left on the device; beside them the line carries the latency of a frame t
 (`ms_per_frame_one_at_a_time_with_d2h`) and, on one GPU, the period of a stream of frames through the job API
 with every image downloaded while the next frame is traced (`ms_per_frame_with_d2h`).
 
-`roofline` prices the trace kernel's algorithmic FLOPs (20 per ray-sphere test, 30 per hit, 250 per shaded
-bounce; counted on the device) against the FP32 vector peak, with the kernel's duration measured by HIP events on
-its launch stream.  That credit is a property of the algorithm, not of the instructions run: the filter spends
-far fewer than 20 FLOP per test, so `roofline.executed` also prices the vector instructions the kernel actually
-issued (modelled from the device counters, or SQ_INSTS_VALU when a counter profile of the workload is committed)
-against the issue peak, a fraction that cannot exceed 1.  `cpu_baseline` times the CPU restatement of the
+`roofline` prices what the trace kernel executed: the vector instructions it issued (SQ_INSTS_VALU x 64 lanes from
+the committed counter profile of the workload, or modelled from this run's device counters when there is none) over
+the kernel's duration (HIP events on its launch stream) against one instruction per lane and clock -- a fraction of
+the hardware that cannot exceed 1.  Beside it: `fp32_flop_frac`, the FP32 arithmetic among those instructions
+(SQ_INSTS_VALU_{FMA,ADD,MUL}_F32, an FMA two operations) against the FP32 vector peak; `lane_utilisation`, the share
+of the lanes of those instructions that were switched on (SQ_THREAD_CYCLES_VALU); and `algorithmic_frac`, the
+algorithm's own credit (20 FLOP per ray-sphere test the reference would run, 30 per hit, 250 per shaded bounce; counted
+on the device) against the same peak -- a measure of how fast the algorithm's work gets done, which passes 1 because
+the filter spends far fewer than 20 FLOP per test.  `cpu_baseline` times the CPU restatement of the
 reference's multithreaded path on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
@@ -109,6 +112,18 @@ def profiled(workload_key):
             return json.load(f).get(workload_key, {})
     except (OSError, ValueError):
         return {}
+
+
+def overlap_profile(workload_key):
+    """The trace kernels of successive frames in the default run of this benchmark (two frames in flight), from the
+    committed rocprofv3 kernel trace of that command (profiles/overlap.json, written by tools/summarise_overlap.py):
+    average duration of a trace kernel, average distance between the starts of successive ones and the time two
+    successive ones run side by side."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "overlap.json")) as f:
+            return json.load(f).get(workload_key)
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_model():
@@ -254,8 +269,11 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         renderer.resolve_device(planes[k % 2].data_ptr(), rgbs[k % 2].data_ptr(), full, stream)
 
+    # slices by runs of pixels: every pixel comes from one rank, so the planes are put together by a gather of each
+    # rank's own runs (1 / N of the bytes, nothing to add); slices by samples need the sum of the whole planes
+    gather = sharding.RunGather(w * h, world, rank, "cpu" if rehearsing else device) if (distributed and by_runs) else None
     pipe = sharding.ReducePipeline(dist, world, host if rehearsing else planes, on_done=resolve, rank=rank,
-                                   context=on_stream)
+                                   context=on_stream, gather=gather)
     frame = [0]
 
     def step():
@@ -304,12 +322,18 @@ def main():
         for _ in range(singles):
             stream = torch.cuda.current_stream().cuda_stream
             renderer.trace_device(scene, p_alone, planes[0].data_ptr(), d_stats[1].data_ptr(), stream)
+            def collect(buf):
+                if gather is not None:
+                    gather.finish(gather.start(dist, buf), buf)
+                else:
+                    sharding.reduce_to_root(dist, buf, world)
+
             if rehearsing:
                 host[0].copy_(planes[0])
-                sharding.reduce_to_root(dist, host[0], world)
+                collect(host[0])
                 planes[0].copy_(host[0])
             else:
-                sharding.reduce_to_root(dist, planes[0], world)
+                collect(planes[0])
             if rank == 0:
                 renderer.resolve_device(planes[0].data_ptr(), rgbs[1].data_ptr(), full, stream)
                 if download:
@@ -396,39 +420,66 @@ def main():
         # vector instructions the kernel issued: counted by SQ_INSTS_VALU (64 lanes each) when this workload has a
         # committed counter profile, else modelled from this run's device counters
         lane_ops = executed_lane_ops(k, scene.sphere_count, args.grid, scene.sphere_count <= 64)
-        executed = None
+        issued, issued_source = None, None
         if prof.get("valu_wave_instructions"):
-            executed = {"valu_lane_ops": 64.0 * prof["valu_wave_instructions"], "source": prof.get("source")}
+            issued, issued_source = 64.0 * prof["valu_wave_instructions"], "SQ_INSTS_VALU x 64, " + str(prof.get("source"))
         elif lane_ops is not None:
-            executed = {"valu_lane_ops": float(lane_ops), "source": "model: device counters x instructions per unit"}
-        if executed is not None:
-            rate = executed["valu_lane_ops"] / (kernel_ms * 1e-3)
-            executed.update({
-                "modelled_valu_lane_ops": float(lane_ops) if lane_ops is not None else None,
-                "achieved": round(rate / 1e12, 2),
-                "peak": round(PEAK_VALU_LANE_OPS / 1e12, 2),
-                "unit": "T lane-instructions/s",
-                "frac": round(rate / PEAK_VALU_LANE_OPS, 4),
-                "note": "vector instructions x 64 lanes over the kernel time, against one instruction per lane and "
-                        "clock (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz); cannot exceed 1, unlike the algorithmic "
-                        "credit of 20 FLOP per test, which the filter undercuts",
-            })
-            reference = measured_issue_rates()
-            if reference:
-                executed["measured_reference"] = reference
+            issued, issued_source = float(lane_ops), "model: this run's device counters x instructions per unit of work"
+        seconds = kernel_ms * 1e-3
+        executed_rate = issued / seconds if issued is not None else None
+        fp32_frac = None
+        if prof.get("fp32_wave_operations"):
+            # FP32 arithmetic among the issued instructions (an FMA two operations), 64 lanes each, over the kernel time
+            fp32_frac = round(64.0 * prof["fp32_wave_operations"] / seconds / (PEAK_FP32_VECTOR_TFLOPS * 1e12), 4)
         if args.grid:
-            bound = "latency (grid walk; achieved/frac credit the brute-force test count and do not apply)"
+            bound = "latency (grid walk: divergent cell walks, spheres read through the L2)"
         else:
             bound = "valu_fp32"
         hbm_bytes = traffic if traffic is not None else column_bytes
         bound_note = ("FP32 vector-ALU issue, neither HBM nor MFMA: %.3f GB of HBM traffic (%s) per launch of %.3g FLOP "
                       "is %.0f FLOP per byte and %.1f GB/s, no matrix work"
                       % (hbm_bytes / 1e9, "PMC counters" if traffic is not None else "algorithmic column sums",
-                         kernel_flop, kernel_flop / max(hbm_bytes, 1), hbm_bytes / (kernel_ms * 1e-3) / 1e9))
+                         kernel_flop, kernel_flop / max(hbm_bytes, 1), hbm_bytes / seconds / 1e9))
+        roofline = {
+            "bound": bound,
+            "bound_note": bound_note,
+            # executed work: vector instructions x 64 lanes over the kernel time, against one instruction per lane and
+            # clock (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz)
+            "achieved": round(executed_rate / 1e12, 2) if executed_rate is not None else None,
+            "peak": round(PEAK_VALU_LANE_OPS / 1e12, 2),
+            "unit": "T lane-instructions/s",
+            "frac": round(executed_rate / PEAK_VALU_LANE_OPS, 4) if executed_rate is not None else None,
+            "frac_source": issued_source,
+            "modelled_frac": round(lane_ops / seconds / PEAK_VALU_LANE_OPS, 4) if lane_ops is not None else None,
+            "fp32_flop_frac": fp32_frac,
+            "lane_utilisation": prof.get("valu_lane_utilisation"),
+            "measured_reference": measured_issue_rates(),
+            # the algorithm's credit (20 FLOP per ray-sphere test the reference would run, 30 per hit, 250 per shaded
+            # bounce) against the FP32 vector peak: how fast the algorithm's work gets done, not how busy the ALUs are
+            "algorithmic_tflops": round(achieved, 2),
+            "algorithmic_peak_tflops": PEAK_FP32_VECTOR_TFLOPS,
+            "algorithmic_frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
+            "executed_over_algorithmic_tests": round(k["sphere_tests"] / max(k["ray_queries"] * scene.sphere_count, 1), 4),
+            "traffic": traffic,
+            "traffic_source": prof.get("source") if traffic is not None else None,
+            "algorithmic_hbm_bytes": column_bytes,
+            "kernel": "trace_kernel",
+            "kernel_ms": round(kernel_ms, 3),
+            "flop_per_launch": kernel_flop,
+            "executed_filter_tests": k["sphere_tests"],
+            "executed_cone_tests": k["cone_tests"],
+            "executed_exact_tests": k["exact_tests"],
+            "lane_trips": k["lane_trips"],
+            "lane_rounds": k["lane_rounds"],
+            "shading_trip_share": round(k["shaded_bounces"] / max(k["lane_trips"], 1), 4),
+            "primary_round_lane_share": round(k["samples"] / max(k["lane_rounds"], 1), 4),
+        }
         collective = {"backend": None, "world_size": 1}
         if distributed:
             collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                          "op": "reduce(SUM, dst=0) of 3*W*H float32 per frame",
+                          "op": ("gather(dst=0) of each rank's own runs of 64 pixels, packed" if gather is not None
+                                 else "reduce(SUM, dst=0) of 3*W*H float32"),
+                          "bytes_per_rank_per_frame": gather.bytes_per_rank if gather is not None else 12 * w * h,
                           "trace_leaves_room_for_it": bool(flags & ffi.FLAG_LEAVE_ROOM)}
         out = {
             "metric": "Msamples/s (camera samples, each traced to its end: primary, scattered and shadow rays)",
@@ -444,9 +495,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s %dx%d, %dx%d SSAA, %d spheres, %s sharded over %d GPU(s), RCCL sum-reduce"
+                "workload": "%s %dx%d, %dx%d SSAA, %d spheres, %s"
                             % (demo_name, w, h, s, s, scene.sphere_count,
-                               "runs of 64 pixels" if (by_runs and distributed) else "samples", world),
+                               "one GPU" if not distributed else
+                               ("runs of 64 pixels dealt out to %d GPUs, RCCL gather of the runs" % world if by_runs else
+                                "samples dealt out to %d GPUs, RCCL sum-reduce" % world)),
                 "scene_seed": 1,
                 "render_seed": 1,
                 "max_depth": 10,
@@ -455,36 +508,18 @@ def main():
                 "collective": collective,
             },
             "value_note": "throughput of a stream of frames, %d in flight, images left in HBM; the latency of one frame "
-                          "is ms_per_frame_one_at_a_time" % lanes,
+                          "is ms_per_frame_one_at_a_time.  With two in flight the trace kernels of successive frames "
+                          "run side by side for a while (kernels_in_stream, from the committed kernel trace of this "
+                          "command): that is how a step can be shorter than the trace kernel launched alone "
+                          "(roofline.kernel_ms)" % lanes,
+            "kernels_in_stream": overlap_profile(key) if lanes == 2 else None,
             "ms_per_frame_one_at_a_time": round(single_ms, 3),
             "ms_per_frame_one_at_a_time_with_d2h": round(single_d2h_ms, 3),
             "ms_per_frame_with_d2h": round(stream_d2h_ms, 3) if stream_d2h_ms is not None else None,
             "mrays_per_s": round(stats["ray_queries"] / (elapsed / args.steps) / 1e6, 1),
             "ray_queries_per_sample": round(stats["ray_queries"] / max(stats["samples"], 1), 3),
             "mean_radiance": round(mean_radiance, 5),
-            "roofline": {
-                "bound": bound,
-                "bound_note": bound_note,
-                "achieved": round(achieved, 2),
-                "peak": PEAK_FP32_VECTOR_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
-                "traffic": traffic,
-                "traffic_source": prof.get("source") if traffic is not None else None,
-                "algorithmic_hbm_bytes": column_bytes,
-                "kernel": "trace_kernel",
-                "kernel_ms": round(kernel_ms, 3),
-                "flop_per_launch": kernel_flop,
-                "executed": executed,
-                "executed_filter_tests": k["sphere_tests"],
-                "executed_cone_tests": k["cone_tests"],
-                "executed_exact_tests": k["exact_tests"],
-                "executed_over_algorithmic_tests": round(
-                    k["sphere_tests"] / max(k["ray_queries"] * scene.sphere_count, 1), 4),
-                "lane_trips": k["lane_trips"],
-                "lane_rounds": k["lane_rounds"],
-                "shading_trip_share": round(k["shaded_bounces"] / max(k["lane_trips"], 1), 4),
-            },
+            "roofline": roofline,
         }
         out["resolve_pass"] = {
             "bound": "hbm",

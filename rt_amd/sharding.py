@@ -3,11 +3,15 @@
 The samples of a frame, numbered (pixel, sx, sy) in the order Frame::ForEachRayImpl visits them
 (ray_tracing/frame.cpp:44-66), are dealt out to the slices in turn: sample (p * S + sx) * S + sy belongs to slice
 number (that index) % slice_count -- or, with pixel_runs, the pixels are: run number (p // 64) belongs to slice
-(that number) % slice_count, with all of its samples.  Every rank traces its slice into planar sums; one sum-reduce to rank 0
-(RCCL over xGMI when the tensors live on GPUs, gloo on CPUs) rebuilds the frame's sums, which rank 0 then
-normalises.  The reference has no counterpart: its CUDA backend is single-GPU (rt_cuda/rt_cuda.cu:80).
+(that number) % slice_count, with all of its samples.  Every rank traces its slice into planar sums; one collective to
+rank 0 (RCCL over xGMI when the tensors live on GPUs, gloo on CPUs) rebuilds the frame's sums, which rank 0 then
+normalises: a sum-reduce of the whole planes for slices by samples (every rank holds a part of every pixel), a gather
+of each rank's own runs for slices by runs of pixels (every pixel comes from one rank: 1 / slice_count of the bytes,
+and no arithmetic).  The reference has no counterpart: its CUDA backend is single-GPU (rt_cuda/rt_cuda.cu:80).
 """
 import contextlib
+
+import torch
 
 
 
@@ -43,8 +47,69 @@ def reduce_to_root(dist, tensor, world_size, root=0):
     return tensor
 
 
+class RunGather:
+    """The collective of slices by runs of pixels: every rank sends the sums of its own runs, packed, to `root`, which
+    puts them where they belong in its planes.  planes: 3 x n_pixels floats (R, G, B planes); rank r owns the pixels
+    p with (p // run_pixels) % world_size == r.  Nothing is added, so the frame on the root holds every pixel exactly
+    as the rank that traced it wrote it.
+
+        g = RunGather(n_pixels, world_size, rank, device)
+        handle = g.start(dist, planes)        # packs this rank's runs and starts the gather (asynchronous)
+        g.finish(handle, planes)              # waits; on the root: the other ranks' runs go into `planes`
+    """
+
+    def __init__(self, n_pixels, world_size, rank, device="cpu", root=0, run_pixels=64):
+        self.n, self.world, self.rank, self.root = n_pixels, max(world_size, 1), rank, root
+        pixel = torch.arange(n_pixels, device=device)
+        owner = (pixel // run_pixels) % self.world
+        counts = [int((owner == r).sum().item()) for r in range(self.world)]
+        self.count = max(counts) if counts else 0  # every rank sends this many pixels (the rest of a short share: padding)
+        self.own = pixel[owner == rank]
+        # on the root: where every other rank's pixels go
+        self.theirs = [pixel[owner == r] if (rank == root and r != root) else None for r in range(self.world)]
+        self.bytes_per_rank = 3 * 4 * self.count
+
+    def pack(self, planes):
+        """This rank's own pixels, 3 x count (a short share padded with zeros)."""
+        packed = planes.new_zeros((3, self.count))
+        packed[:, : self.own.numel()] = planes.view(3, self.n)[:, self.own]
+        return packed
+
+    def unpack(self, planes, received):
+        """On the root: received[r] (what rank r packed) goes where rank r's pixels belong."""
+        view = planes.view(3, self.n)
+        for r, where in enumerate(self.theirs):
+            if where is not None and where.numel():
+                view[:, where] = received[r][:, : where.numel()]
+        return planes
+
+    def start(self, dist, planes):
+        if self.world == 1:
+            return None
+        packed = self.pack(planes)
+        received = [torch.empty_like(packed) for _ in range(self.world)] if self.rank == self.root else None
+        work = dist.gather(packed, received, dst=self.root, async_op=True)
+        return work, packed, received
+
+    def finish(self, handle, planes):
+        if handle is None:
+            return planes
+        work, _, received = handle
+        work.wait()  # on GPUs: makes the current stream wait for the collective
+        if self.rank == self.root:
+            self.unpack(planes, received)
+        return planes
+
+
+def gather_runs_to_root(dist, planes, n_pixels, world_size, rank, root=0):
+    """One frame's slices by runs of pixels put together on `root` (in place); a no-op for one rank."""
+    g = RunGather(n_pixels, world_size, rank, planes.device, root)
+    return g.finish(g.start(dist, planes), planes)
+
+
 class ReducePipeline:
-    """Sum-reduce of successive frames to rank `root`, one frame behind the producer: while the planes of frame
+    """The collective of successive frames to rank `root` (a sum-reduce; with `gather`, a RunGather, the gather of
+    slices by runs of pixels instead), one frame behind the producer: while the planes of frame
     k are being reduced, the caller already fills the other buffer with frame k + 1.
 
         buf = pipe.acquire(k)      # the buffer frame k goes into (its previous reduce has been waited for)
@@ -57,10 +122,11 @@ class ReducePipeline:
     issued in frame order by every rank, as torch.distributed requires.
     """
 
-    def __init__(self, dist, world_size, buffers, on_done=None, root=0, rank=0, context=None):
+    def __init__(self, dist, world_size, buffers, on_done=None, root=0, rank=0, context=None, gather=None):
         assert len(buffers) >= 2
         self.dist, self.world, self.buffers, self.on_done, self.root, self.rank = (
             dist, max(world_size, 1), buffers, on_done, root, rank)
+        self.gather = gather
         # context(k): what frame k is retired under (on GPUs: the stream that owns the frame's buffer, so that
         # the wait and on_done are ordered before the next use of that buffer); submit(k) is the caller's to wrap
         self.context = context if context is not None else (lambda k: contextlib.nullcontext())
@@ -75,7 +141,9 @@ class ReducePipeline:
     def submit(self, k):
         buf = self.buffers[k % len(self.buffers)]
         work = None
-        if self.world > 1:
+        if self.world > 1 and self.gather is not None:
+            work = self.gather.start(self.dist, buf)
+        elif self.world > 1:
             work = self.dist.reduce(buf, dst=self.root, op=self.dist.ReduceOp.SUM, async_op=True)
         self.pending[k] = work
         if self.world == 1:
@@ -90,7 +158,9 @@ class ReducePipeline:
     def _retire(self, k):
         work = self.pending.pop(k)
         with self.context(k):
-            if work is not None:
+            if work is not None and self.gather is not None:
+                self.gather.finish(work, self.buffers[k % len(self.buffers)])
+            elif work is not None:
                 work.wait()  # on GPUs: makes the current stream wait for the collective
             if self.on_done is not None and self.rank == self.root:
                 self.on_done(k, self.buffers[k % len(self.buffers)])

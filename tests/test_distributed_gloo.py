@@ -104,3 +104,52 @@ def test_reduce_pipeline_with_one_rank():
         pipe.submit(k)
     pipe.drain()
     assert done == [(0, 1.0), (1, 2.0), (2, 3.0)]
+
+
+def _gather_worker(rank, world, port, out_path):
+    for path in (ROOT, os.path.join(ROOT, "tests")):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    import emu_ffi
+    from rt_amd import ffi, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = ffi.Scene.demo(1, 1)
+    w, h = 50, 37  # 1850 pixels: 29 runs of 64, the last one short, and an odd number of them for two ranks
+    rgb, _ = emu_ffi.render(scene, ffi.params(w, h, 2, seed=5))
+    whole = torch.from_numpy(np.ascontiguousarray(rgb.reshape(-1, 3).T.astype(np.float32))).reshape(-1)  # 3 planes
+    # what a slice by runs of pixels looks like: this rank's pixels complete, the others' zero
+    pixel = torch.arange(w * h)
+    mine = torch.tensor([sharding.run_owner(int(p), world) == rank for p in pixel])
+    planes = (whole.view(3, -1) * mine).reshape(-1).clone()
+    frames = [planes.clone(), planes.clone()]
+    # once directly ...
+    sharding.gather_runs_to_root(dist, frames[0], w * h, world, rank)
+    # ... and once through the double-buffered pipeline bench.py uses
+    done = []
+    g = sharding.RunGather(w * h, world, rank)
+    pipe = sharding.ReducePipeline(dist, world, [frames[1], planes.clone()], on_done=lambda k, b: done.append(b.clone()),
+                                   rank=rank, gather=g)
+    pipe.acquire(0)
+    pipe.submit(0)
+    pipe.drain()
+    if rank == 0:
+        assert g.bytes_per_rank == 12 * (14 * 64 + 58)  # 15 of the 29 runs are rank 0's, the last one 58 pixels long
+        assert torch.equal(frames[0], whole) and torch.equal(done[0], whole)  # bit for bit: nothing was added
+        np.save(out_path, frames[0].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_their_runs_of_pixels(tmp_path):
+    """Slices by runs of 64 pixels are put together by a gather of each rank's own runs, not by a sum: the frame on
+    the root is the one-rank frame bit for bit, for a frame whose last run is short and whose runs do not divide
+    evenly among the ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "gathered.npy")
+    mp.spawn(_gather_worker, args=(2, port, out_path), nprocs=2, join=True)
+    assert np.isfinite(np.load(out_path)).all()

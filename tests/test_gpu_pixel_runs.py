@@ -97,3 +97,32 @@ def test_more_slices_than_runs(hip, ffi, scenes):
             assert not mine.any() and c[0] == 0
         total += mine
     assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
+
+
+def test_gather_of_each_slices_runs_rebuilds_the_frame(hip, ffi, scenes):
+    """What bench.py's ranks exchange: every rank packs the sums of its own runs (rt_amd/sharding.py RunGather), the root
+    puts the packed runs where they belong.  The frame on the root is the one-GPU frame bit for bit, for a frame
+    whose runs do not divide evenly and whose last run is short."""
+    import torch
+
+    from rt_amd import sharding
+
+    scene = scenes(1)
+    w, h, s, world = 250, 131, 4, 3
+    n = w * h
+    stream = torch.cuda.current_stream().cuda_stream
+    whole = torch.empty(3 * n, dtype=torch.float32, device="cuda")
+    hip.trace_device(scene, ffi.params(w, h, s, seed=7), whole.data_ptr(), None, stream)
+    slices, packed = [], []
+    for rank in range(world):
+        p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=7), rank, world, pixel_runs=True)
+        planes = torch.full((3 * n,), float("nan"), dtype=torch.float32, device="cuda")
+        hip.trace_device(scene, p, planes.data_ptr(), None, stream)
+        torch.cuda.synchronize()
+        slices.append(planes)
+        g = sharding.RunGather(n, world, rank, "cuda")
+        packed.append(g.pack(planes))
+        assert g.bytes_per_rank <= 12 * (n // world + 64)
+    root = sharding.RunGather(n, world, 0, "cuda")
+    root.unpack(slices[0], packed)
+    assert torch.equal(slices[0], whole)

@@ -1,9 +1,13 @@
 """Condenses the kernel trace of tools/overlap_trace.sh into profiles/<tag>_overlap.txt: one line per trace-kernel
-launch of the timed region with its hardware queue, start and end.
+launch of the timed region with its hardware queue, start and end -- and into the entry of profiles/overlap.json
+that bench.py quotes as `kernels_in_stream`: over the launches that ran beside their successor, the average
+duration of a trace kernel, the average distance between successive starts and the average time two successive
+kernels ran side by side.
 
 python tools/summarise_overlap.py <tag>
 """
 import csv
+import json
 import os
 import sys
 
@@ -31,3 +35,29 @@ with open(out, "w") as f:
         prev = s
     f.write("\nbench line of the same run:\n" + line)
 print(open(out).read())
+
+# the launches that ran beside their successor (the stream of frames; the launches after it run one at a time)
+spans = [(int(r["Start_Timestamp"]) / 1e6, int(r["End_Timestamp"]) / 1e6) for r in rows]
+median = sorted(e - s for s, e in spans)[len(spans) // 2]
+# (not the first launches of the process, which include loading the code object)
+pairs = [(a, b) for a, b in zip(spans, spans[1:]) if b[0] < a[1] and max(a[1] - a[0], b[1] - b[0]) < 1.3 * median]
+if pairs:
+    bench = json.loads(line)
+    cfg = bench["config"]["workload"]
+    key = "demo1_1920x1080_s16_g1"  # the default command of tools/overlap_trace.sh
+    path = os.path.join(ROOT, "profiles", "overlap.json")
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[key] = {
+        "kernel_ms": round(sum(a[1] - a[0] for a, _ in pairs) / len(pairs), 3),
+        "start_to_start_ms": round(sum(b[0] - a[0] for a, b in pairs) / len(pairs), 3),
+        "side_by_side_ms": round(sum(a[1] - b[0] for a, b in pairs) / len(pairs), 3),
+        "pairs": len(pairs),
+        "workload": cfg,
+        "source": "profiles/%s_overlap.txt" % tag,
+    }
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1)
+    print(data[key])

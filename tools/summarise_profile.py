@@ -35,8 +35,10 @@ with open(os.path.join(dst, tag + "_pmc_summary.txt"), "w") as out:
               "row, repeat, spheres of demo 3, flags), collected by tools/profile.sh; values summed over the dispatches of\n"
               "each kernel in the run (one trace launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them\n"
               "(FETCH_SIZE uncorrected).\n\n" % " ".join(workload[:4] + ["1", workload[4], "2" if grid else "0"]))
-    for name in ("sq1", "sq2", "fetch", "write"):
+    for name in ("sq1", "sq2", "sq3", "sq4", "fetch", "write"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        if not os.path.exists(os.path.join(src, name, name + "_counter_collection.csv")):
+            continue  # (profiles taken before the pass existed)
         with open(os.path.join(src, name, name + "_counter_collection.csv")) as f:
             for r in csv.DictReader(f):
                 m = re.search(r"(\w+_kernel(<[^>]*>)?|__amd_rocclr_\w+)", r["Kernel_Name"])
@@ -48,7 +50,8 @@ with open(os.path.join(dst, tag + "_pmc_summary.txt"), "w") as out:
             for c, x in sorted(counters.items()):
                 out.write("    %-28s %.0f\n" % (c, x))
                 if "trace_kernel" in kernel:
-                    totals[c] = x
+                    totals[(name, c)] = x
+                    totals.setdefault(c, x)  # the first pass that holds a counter names it (SQ_INSTS_VALU is in three)
 
 traffic_path = os.path.join(dst, "traffic.json")
 traffic = {}
@@ -64,6 +67,17 @@ traffic[key] = {
     "valu_wave_instructions": totals.get("SQ_INSTS_VALU"),
     "source": "profiles/%s_pmc_summary.txt" % tag,
 }
+if ("sq3", "SQ_INSTS_VALU_FMA_F32") in totals:
+    # FP32 arithmetic among the vector instructions: an FMA is two operations per lane
+    traffic[key]["fp32_wave_operations"] = (2.0 * totals["SQ_INSTS_VALU_FMA_F32"] + totals["SQ_INSTS_VALU_ADD_F32"] +
+                                            totals["SQ_INSTS_VALU_MUL_F32"])
+    traffic[key]["valu_wave_instructions_in_that_pass"] = totals[("sq3", "SQ_INSTS_VALU")]
+if ("sq4", "SQ_THREAD_CYCLES_VALU") in totals:
+    # lanes switched on per vector instruction, as rocprofv3 defines VALUUtilization: thread-cycles over (cycles
+    # spent on vector instructions x 64 lanes)
+    cycles = totals.get(("sq4", "SQ_ACTIVE_INST_VALU"))
+    traffic[key]["valu_lane_utilisation"] = round(totals[("sq4", "SQ_THREAD_CYCLES_VALU")] / (64.0 * cycles), 4) if cycles else None
 with open(traffic_path, "w") as f:
     json.dump(traffic, f, indent=1)
-print("profiles/%s_* written; trace kernel: %s" % (tag, {k: totals[k] for k in sorted(totals)}))
+print("profiles/%s_* written; trace kernel: %s" % (tag, {k: totals[k] for k in sorted(k for k in totals if isinstance(k, str))}))
+print(traffic[key])
