@@ -52,8 +52,40 @@ oracle/liboracle_frame.so: oracle/frame_cpu.cpp oracle/librt_oracle.so $(HOST_HD
 tests/emu/libcore_emu.so: tests/emu/core_emu.cpp $(CORE_HDRS)
 	$(CXX) -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Wl,-Bsymbolic -Iinclude -Irt_amd/csrc tests/emu/core_emu.cpp -o $@
 
+# Sanitizer builds of everything that runs on the host (the checkers, the host mirror and its C ABI), and the CPU
+# tests under them.  For the build container only: no GPU is involved (librt_host.so links the ordinary librt_hip.so,
+# which loads without one).  Python itself is not instrumented, so the sanitizer runtime is preloaded.
+#   make san        AddressSanitizer + UndefinedBehaviorSanitizer, then ThreadSanitizer
+SAN_TESTS := tests/test_oracle_golden.py tests/test_oracle_properties.py tests/test_emu_vs_oracle.py tests/test_host.py tests/test_sharding_runs.py
+SAN_HOST_SRC := rt_amd/host/rt_host_capi.cpp rt_amd/host/rt_hip/demo_frame_hip.cpp
+san: san-asan san-tsan
+
+build/san-%/.built: oracle/rt_oracle.c oracle/rt_oracle.h oracle/frame_cpu.cpp tests/emu/core_emu.cpp $(SAN_HOST_SRC) $(CORE_HDRS) $(HOST_HDRS) $(LIB)/librt_hip.so
+	@mkdir -p $(@D)
+	gcc -O1 -g -std=c99 -ffp-contract=off -fno-fast-math -fPIC -pthread $(SAN_FLAGS) -shared oracle/rt_oracle.c -o $(@D)/librt_oracle.so -lm
+	cp $(@D)/librt_oracle.so $(@D)/librt_oracle_o3.so
+	$(CXX) -O1 -g -std=c++17 -ffp-contract=off -fPIC -pthread $(SAN_FLAGS) -Ioracle -Iinclude -Irt_amd/host -shared oracle/frame_cpu.cpp \
+	    -L$(@D) -lrt_oracle -Wl,-rpath,'$$ORIGIN' -o $(@D)/liboracle_frame.so
+	$(CXX) -O1 -g -std=c++17 -ffp-contract=off -fPIC $(SAN_FLAGS) -shared -Wl,-Bsymbolic -Iinclude -Irt_amd/csrc tests/emu/core_emu.cpp -o $(@D)/libcore_emu.so
+	cp $(LIB)/librt_hip.so $(@D)/librt_hip.so
+	$(CXX) -O1 -g -std=c++17 -ffp-contract=off -fPIC $(SAN_FLAGS) -Iinclude -Irt_amd/host -shared $(SAN_HOST_SRC) \
+	    -L$(@D) -lrt_hip -Wl,-rpath,'$$ORIGIN' -o $(@D)/librt_host.so
+	@touch $@
+
+build/san-asan/.built: SAN_FLAGS := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
+build/san-tsan/.built: SAN_FLAGS := -fsanitize=thread -fno-omit-frame-pointer
+
+san-asan: build/san-asan/.built
+	LD_PRELOAD=$$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+	    RT_CHECKER_LIB_DIR=$(CURDIR)/build/san-asan RT_AMD_LIB_DIR=$(CURDIR)/build/san-asan python -m pytest $(SAN_TESTS) -x -q -p no:cacheprovider
+
+san-tsan: build/san-tsan/.built
+	LD_PRELOAD=$$(gcc -print-file-name=libtsan.so) TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 \
+	    RT_CHECKER_LIB_DIR=$(CURDIR)/build/san-tsan RT_AMD_LIB_DIR=$(CURDIR)/build/san-tsan python -m pytest $(SAN_TESTS) -x -q -p no:cacheprovider
+
 clean:
 	rm -f $(LIB)/*.so $(BIN)/rt_cli tests/emu/libcore_emu.so
+	rm -rf build
 	$(MAKE) -C oracle clean
 
-.PHONY: all checkers prof clean
+.PHONY: all checkers prof clean san san-asan san-tsan

@@ -13,7 +13,9 @@ import numpy as np
 from rt_amd.ffi import Camera, Light, Material, Stats, TraceParams  # layouts only
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "librt_oracle.so")
+# RT_CHECKER_LIB_DIR: another directory of built checker libraries (the sanitizer builds of `make san`)
+_LIB_DIR = os.environ.get("RT_CHECKER_LIB_DIR") or _HERE
+_PATH = os.path.join(_LIB_DIR, "librt_oracle.so")
 
 
 class OrcHit(C.Structure):
@@ -121,7 +123,7 @@ def orc_scene(scene):
     return s
 
 
-_O3_PATH = os.path.join(_HERE, "librt_oracle_o3.so")
+_O3_PATH = os.path.join(_LIB_DIR, "librt_oracle_o3.so")
 _o3 = None
 
 
@@ -167,7 +169,7 @@ def render_rows(scene, p, row_begin, row_end, threads=None):
     return rgb[row_begin:row_end].copy(), stats
 
 
-_FRAME_PATH = os.path.join(_HERE, "liboracle_frame.so")
+_FRAME_PATH = os.path.join(_LIB_DIR, "liboracle_frame.so")
 _frame_lib = None
 
 

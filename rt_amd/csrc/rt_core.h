@@ -749,7 +749,11 @@ RT_FN void scatter(const MaterialView & m, f3 rd, f3 n, f3 ball, float xi, f3 & 
 // DirectionalLight::GetSpecular, ray_tracing/directional_light.cpp:37-60.  The half vector and the cosines are
 // computed exactly (the Beckmann exponent multiplies their rounding by up to 1 / 0.03^2); the three quotients
 // and the exponential behind them only scale the result and use the hardware reciprocal and exp2 (~1e-6).  The
-// clamps and minima are the hardware's (one instruction each): the same values for every operand but a NaN.
+// clamps and minima are the hardware's (one instruction each): the same values for every operand but a NaN, for which
+// glm::clamp and std::min (compare and select) hand the NaN through and these give the lower bound, or the other
+// operand.  A NaN arises in one case: a light that shines exactly along the viewing ray towards the camera
+// (ldir + rd == 0), whose half vector is the normalisation of zero.  The reference's sample is a NaN then; here the
+// specular term of that hit is 0 and the sample finite (tests/test_emu_vs_oracle.py pins both).
 RT_FN f3 specular(f3 ldir, f3 lcol, f3 albedo, const MaterialView & m, f3 rd, f3 n, bool library_math)
 {
   float const vdn = hw_clamp(dot3(-rd, n), 0.0f, 1.0f);

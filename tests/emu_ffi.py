@@ -11,7 +11,8 @@ import numpy as np
 from rt_amd.ffi import Camera, TraceParams
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_PATH = os.path.join(_ROOT, "tests", "emu", "libcore_emu.so")
+# RT_CHECKER_LIB_DIR: another directory of built checker libraries (the sanitizer builds of `make san`)
+_PATH = os.path.join(os.environ.get("RT_CHECKER_LIB_DIR") or os.path.join(_ROOT, "tests", "emu"), "libcore_emu.so")
 _lib = None
 
 

@@ -297,3 +297,30 @@ def test_shade_filter_far_from_the_scene_centre(oracle, ffi, gap):
             for key in ("samples", "ray_queries", "hit_queries", "shaded_bounces"):
                 assert es[key] == getattr(rs, key), key
     assert rs.hit_queries > 0.1 * rs.samples  # the spheres are in view
+
+
+def test_view_direction_exactly_opposite_the_light(oracle, ffi):
+    """The one place the kernel's arithmetic departs from the reference's on purpose: a light that shines exactly
+    along the viewing ray, towards the camera, makes the half vector of DirectionalLight::GetSpecular
+    (ray_tracing/directional_light.cpp:42) the normalisation of a zero vector.  glm's clamp and std::min hand the NaN
+    through, so the reference (and the oracle) give that sample a NaN colour; the kernel clamps with the hardware's
+    median-of-three and minimum, which give the lower bound for a NaN: the specular term of that hit is 0 and the
+    sample is finite."""
+    import ctypes as C
+
+    lib = oracle.load()
+    camera = dict(position=(0.0, 0.0, -5.0), direction=(0.1, -0.2, 1.0))
+    probe = ffi.Scene.build([], [], [], camera)
+    d = oracle.F3()
+    lib.orc_primary_direction(C.byref(probe.camera), 1, 1, 1, 0, 0, 0, 0, C.byref(d))
+    rd = np.array(list(d), dtype=np.float32)
+    centre = np.float32([0.0, 0.0, -5.0]) + rd * np.float32(4.0)  # a sphere the one ray of the frame hits head-on
+    scene = ffi.Scene.build([(float(centre[0]), float(centre[1]), float(centre[2]), 1.0, 0)], [(0, (0.6, 0.5, 0.4), 0.7, 0.0)],
+                            [(tuple(float(-x) for x in rd), (1.0, 1.0, 1.0))], camera)
+    p = ffi.params(1, 1, 1, flags=ffi.FLAG_DETERMINISTIC, max_depth=1)
+    ref, rs = oracle.render(scene, p, 1)
+    out, es = emu_ffi.render(scene, p, forward=True)
+    assert rs.hit_queries >= 1 and es["shaded_bounces"] == rs.shaded_bounces == 1
+    assert np.isnan(ref).all()
+    # the surface faces away from the light (no diffuse term) and the specular term is 0: half the albedo
+    np.testing.assert_allclose(out[0, 0], 0.5 * np.float32([0.6, 0.5, 0.4]), rtol=1e-6)
