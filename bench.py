@@ -272,6 +272,24 @@ def main():
     # slices by runs of pixels: every pixel comes from one rank, so the planes are put together by a gather of each
     # rank's own runs (1 / N of the bytes, nothing to add); slices by samples need the sum of the whole planes
     gather = sharding.RunGather(w * h, world, rank, "cpu" if rehearsing else device) if (distributed and by_runs) else None
+    gather_note = None
+    if gather is not None:
+        # one gather before anything is timed: a backend that cannot do it is found out here, and the run goes on
+        # with the sum-reduce (the planes of the other ranks' pixels are zero, so the sum is the same frame)
+        try:
+            probe = (host if rehearsing else planes)[0]
+            probe.zero_()
+            gather.finish(gather.start(dist, probe), probe)
+            if not rehearsing:
+                torch.cuda.synchronize()
+            ok = torch.ones(1, dtype=torch.int32, device="cpu" if rehearsing else device)
+        except Exception as e:  # noqa: BLE001 (whatever the backend raises)
+            gather_note = "gather failed (%s: %s), sum-reduce instead" % (type(e).__name__, str(e)[:120])
+            ok = torch.zeros(1, dtype=torch.int32, device="cpu" if rehearsing else device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks take the same path
+        if int(ok.item()) == 0:
+            gather = None
+            gather_note = gather_note or "gather failed on another rank, sum-reduce instead"
     pipe = sharding.ReducePipeline(dist, world, host if rehearsing else planes, on_done=resolve, rank=rank,
                                    context=on_stream, gather=gather)
     frame = [0]
@@ -481,6 +499,8 @@ def main():
                                  else "reduce(SUM, dst=0) of 3*W*H float32"),
                           "bytes_per_rank_per_frame": gather.bytes_per_rank if gather is not None else 12 * w * h,
                           "trace_leaves_room_for_it": bool(flags & ffi.FLAG_LEAVE_ROOM)}
+            if gather_note:
+                collective["note"] = gather_note
         out = {
             "metric": "Msamples/s (camera samples, each traced to its end: primary, scattered and shadow rays)",
             "value": round(total_samples / (elapsed / args.steps) / 1e6, 2),
@@ -498,8 +518,8 @@ def main():
                 "workload": "%s %dx%d, %dx%d SSAA, %d spheres, %s"
                             % (demo_name, w, h, s, s, scene.sphere_count,
                                "one GPU" if not distributed else
-                               ("runs of 64 pixels dealt out to %d GPUs, RCCL gather of the runs" % world if by_runs else
-                                "samples dealt out to %d GPUs, RCCL sum-reduce" % world)),
+                               ("runs of 64 pixels dealt out to %d GPUs, RCCL %s" % (world, "gather of the runs" if gather is not None else "sum-reduce")
+                                if by_runs else "samples dealt out to %d GPUs, RCCL sum-reduce" % world)),
                 "scene_seed": 1,
                 "render_seed": 1,
                 "max_depth": 10,

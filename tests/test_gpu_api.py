@@ -249,8 +249,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert "workload" in out["config"] and "model" not in out["config"]
     assert out["value"] == pytest.approx(320 * 180 * 16 / (out["ms_per_step"] * 1e-3) / 1e6, rel=5e-3)
     roof = out["roofline"]
-    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=2e-4) and roof["unit"] == "TFLOP/s"
-    assert roof["kernel_ms"] > 0 and roof["traffic"] is None  # traffic is only known for the profiled workload
+    # the top-level fraction is executed work (vector instructions issued against the issue peak): at most 1
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3) and roof["unit"] == "T lane-instructions/s"
+    assert 0.0 < roof["frac"] <= 1.0 and roof["frac_source"].startswith("model")  # no counter profile of this workload
+    assert roof["algorithmic_frac"] == pytest.approx(roof["algorithmic_tflops"] / roof["algorithmic_peak_tflops"], abs=2e-4)
+    assert roof["kernel_ms"] > 0 and roof["traffic"] is None  # traffic is only known for the profiled workloads
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
 
