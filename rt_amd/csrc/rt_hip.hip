@@ -11,6 +11,9 @@
 //                        reverse loop over a 10-entry stack per lane in LDS (40 KB per block).
 //   trace_kernel<*, *, true>   scenes with one light: no shading state carried from trip to trip.
 //   trace_kernel_grid    the same loop with rays walking the scene's uniform grid (RT_HIP_FLAG_GRID).
+//   trace_kernel<*, true, *, false, true>  the kForward kernels once more, adding up the pixels themselves: a wave
+//                        keeps the column sums of its queue windows in LDS (PixelRing) and writes 12 bytes per pixel
+//                        when a window is done (RT_HIP_FLAG_KERNEL_SUMS; an option: these kernels run 3-5 % longer).
 //   fold_kernel          completes the sums of columns whose last samples were traced by other lanes of the
 //                        owner's wave (sample sharing at the end of the queue).
 //   trace_kernel<*, *, false, true>  the kernels for any number of lights built with the compiler's general IEEE
@@ -19,12 +22,15 @@
 //   colsum_lds_kernel    the same for the common sample counts: whole-line loads, transposed through LDS.
 //   resolve_kernel       planar un-normalised sums -> interleaved RGB * 1/S^2 (ray_tracing/frame.cpp:43,67),
 //                        16 bytes per lane per access.  These are the HBM-bound passes.
+//   zero_kernel          clears a job's column sums (what a snapshot may read before the trace has written it).
 //   exact_math_check_kernel  self-check of the short correctly rounded sequences (rt_hip_check_exact_math).
 //
 //   camtab_kernel        per-launch set-up: table of the primary-ray filter (one entry per sphere), counters reset.
 //
 // LDS per block: the resident scene (56 B per sphere, 48 B per material and light) and 8 KB of prepared
-// columns, or one 20 KB staging tile for scenes above kResidentSpheres spheres.
+// columns, or one 20 KB staging tile for scenes above kResidentSpheres spheres; with RT_HIP_FLAG_KERNEL_SUMS also the
+// waves' rings (ring_bytes_per_wave: 0.4 KB + 768 B per window a wave may keep unfinished, as many as fit beside
+// the rest without costing a block per compute unit).
 #include "rt_core.h"
 #include "rt_hip.h"
 #include "rt_prep.h"
