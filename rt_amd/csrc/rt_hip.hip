@@ -375,6 +375,49 @@ struct PixelRing
   }
 };
 
+// Pixel sums at the end of a wave's life (kernels with kLog; the resident layout only).  The kernel leaves column sums
+// as usual, and every wave notes its queue reservations in LDS -- one word each, nothing else happens inside the loop.
+// When the wave has no more work, every column it was handed is in memory: it completes the columns whose last
+// samples other lanes of it traced (the fold pass), then goes through its reservations window by window, adds each
+// pixel's columns in increasing sx and writes the pixel sums (the accumulate pass) -- the same additions in the same
+// order as the two passes, by the wave that wrote the columns, with no launch that has to find block slots between
+// two frames of a stream.  Per wave, at the start of the block's dynamic LDS: kLogEntries reservation words
+// (queue position | windows - 1; positions are multiples of the 64-item window), then two words per lane for the one
+// column a lane may leave with shared samples (its slot and the first shared sample; a lane owns at most one such
+// column per launch, because they only arise once the wave's queue is used up and no lane gets another column).
+// A wave whose log is full takes no more reservations; the host sizes reservations so that this stays theory, and
+// checks that the logs of a launch can hold every reservation the queue can be cut into.
+//
+// What the end of a wave needs of the launch's arguments is parked in LDS when the block starts (EndArgs, in front of
+// the logs) and read back from there: an argument that is used after the main loop would otherwise sit in a scalar
+// register across it, and the loop has none to spare.
+constexpr uint32_t kLogEntries = 384;
+constexpr uint32_t kLogWords = kLogEntries + 2u * 64u;
+constexpr uint32_t kLogMaxWindows = 64;   // windows of a reservation (6 bits of the word)
+struct EndArgs
+{
+  float * partial;
+  float * planes;
+  const float * shared;
+  uint32_t n_pixels, n_items, queue_items, run_items, run_stride, run_first, s_row, slice_count, share_depth;
+  uint32_t log_entries;  // reservations a wave may note (<= kLogEntries; fewer in tests of what happens when a log is full)
+};
+static_assert(sizeof(EndArgs) == 64, "EndArgs is read back word by word");
+constexpr size_t kLogBlockBytes = sizeof(EndArgs) + sizeof(uint32_t) * kLogWords * (kBlock / 64);
+__device__ __forceinline__ uint32_t log_entries()
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  return reinterpret_cast<const EndArgs *>(lds_raw)->log_entries;
+}
+__device__ __forceinline__ uint32_t * wave_log()
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  // (worked out where it is used, every time: a pointer computed once ahead of the main loop would live across it)
+  uint32_t wave = threadIdx.x / 64u;
+  asm volatile("" : "+v"(wave));
+  return reinterpret_cast<uint32_t *>(lds_raw + sizeof(EndArgs)) + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) * kLogWords;
+}
+
 struct ItemPool
 {
   uint32_t next = 0, end = 0;  // the current window (queue positions), wave-uniform
@@ -384,7 +427,9 @@ struct ItemPool
   uint32_t last_size = 0;      // size of the wave's previous reservation
   bool exhausted = false;      // the last reservation lay past the end of the queue: nothing more will come
 
-  // Opens the next window: the rest of the reservation, or a new reservation.
+  // Opens the next window: the rest of the reservation, or a new reservation.  kLog: the wave notes its reservations
+  // (wave_log) and stops taking them when the log is full.
+  template <bool kLog>
   __device__ __forceinline__ void refill(const TraceArgs & A)
   {
     if (end == reserved_end)
@@ -410,9 +455,13 @@ struct ItemPool
         // A cancelled job stops at a reservation: the wave is sent past the end of the queue.  The flag may
         // live in host memory, a slow read, so only every kCancelPoll-th reservation looks at it.
         bool cancelled = false;
-        if ((refills % kCancelPoll) == 0u)
+        if constexpr (kLog)
+          cancelled = refills >= log_entries();  // the log is full: the wave is sent past the end of the queue too
+        if (!cancelled && (refills % kCancelPoll) == 0u)
           cancelled = __hip_atomic_load(A.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
         base = cancelled ? 0xF0000000u : atomicAdd(A.queue_counter, size);
+        if (kLog && refills < kLogEntries)
+          wave_log()[refills] = base | (size / kItemBatch - 1u);
       }
       refills += 1u;
       end = __builtin_amdgcn_readfirstlane(base);
@@ -435,7 +484,7 @@ struct ItemPool
   // TraceArgs::ring_errors.
   // L, info: the lane's state, and what the call that asks for the window has handed the lane so far (a column
   // handed out a moment ago is not in L yet).
-  template <bool kFused>
+  template <bool kFused, bool kLog>
   __device__ __forceinline__ bool open(const TraceArgs & A, PixelRing & ring, const Lane & L, const ItemInfo & info)
   {
     if constexpr (kFused)
@@ -453,14 +502,14 @@ struct ItemPool
       next = end;
       return true;
     }
-    refill(A);
+    refill<kLog>(A);
     if (kFused && next < A.queue_items)
       ring.opened(min(kItemBatch, A.queue_items - next), next + delta);
     return true;
   }
 
   // Hands the next queue positions to the lanes that need one: info.pos (the item) and info.slot.
-  template <bool kFused>
+  template <bool kFused, bool kLog = false>
   __device__ __forceinline__ void fetch(const TraceArgs & A, PixelRing & ring, const Lane & L, bool need, ItemInfo & info)
   {
     for (;;)
@@ -472,7 +521,7 @@ struct ItemPool
       {
         if (exhausted)
           break;
-        if (!open<kFused>(A, ring, L, info))
+        if (!open<kFused, kLog>(A, ring, L, info))
         {
           info.stalled = true;
           break;
@@ -567,7 +616,7 @@ __device__ __forceinline__ void append_split(const TraceArgs & A, uint32_t slot,
 }
 
 // The whole scene is resident in LDS; waves never wait for each other.
-template <bool kLibMath, bool kFused>
+template <bool kLibMath, bool kFused, bool kLog = false>
 struct WaveEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
@@ -591,7 +640,18 @@ struct WaveEnv
   __device__ __forceinline__ bool any_wave(bool p) const { return __any(p) != 0; }
   __device__ __forceinline__ bool endgame() const { return pool.exhausted; }
   __device__ __forceinline__ void share(Lane & L) const { share_samples<kFused>(A, L); }
-  __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const { append_split(A, slot, sy); }
+  __device__ __forceinline__ void record_split(uint32_t slot, uint32_t sy) const
+  {
+    if constexpr (kLog)
+    {
+      // the wave completes the column itself when it has no more work (wave_sums)
+      uint32_t * const mine = wave_log() + kLogEntries + 2u * lane_here();
+      mine[0] = slot;
+      mine[1] = sy;
+    }
+    else
+      append_split(A, slot, sy);
+  }
   // (kFused: a window holds whole pixels and starts at one, so a column's place in its window gives sx; a shared
   // sample carries the owner's sx in bits 9..14 of its slot)
   __device__ __forceinline__ uint32_t column_sx(const Lane & L) const
@@ -631,7 +691,7 @@ struct WaveEnv
     info.filter_tests = 0u;
     if (A.column_masks == 0u)
     {
-      pool.template fetch<kFused>(A, ring, L, need, info);
+      pool.template fetch<kFused, kLog>(A, ring, L, need, info);
       return;
     }
     uint32_t const lane = lane_here();
@@ -644,7 +704,7 @@ struct WaveEnv
       {
         if (pool.exhausted)
           break;
-        if (!pool.template open<kFused>(A, ring, L, info))
+        if (!pool.template open<kFused, kLog>(A, ring, L, info))
         {
           info.stalled = true;
           break;
@@ -865,16 +925,244 @@ __device__ __forceinline__ void flush_counters(const TraceArgs & A, LaneCounters
 #endif
 }
 
+// Slices by runs of pixels, kernels that take the pixel sums at the end of their waves: the sums of the pixels other
+// slices trace are zero; the launch's waves share those runs out among themselves (64 lanes, one run of one plane).
+__device__ __forceinline__ void zero_other_runs(const TraceArgs & A)
+{
+  if (A.run_items == 0u)
+    return;
+  uint32_t const lane = __lane_id();
+  uint32_t const run_pixels = A.run_items / A.s_row;
+  uint32_t const n_runs = (A.n_pixels + run_pixels - 1u) / run_pixels;
+  uint32_t const waves = gridDim.x * (kBlock / 64u);
+  for (uint32_t k = blockIdx.x * (kBlock / 64u) + wave_in_block(); k < 3u * n_runs; k += waves)
+  {
+    uint32_t const plane = k / n_runs, run = k - plane * n_runs;
+    if (run % A.run_stride == A.run_first)
+      continue;
+    for (uint32_t i = lane; i < run_pixels; i += 64u)
+    {
+      uint32_t const px = run * run_pixels + i;
+      if (px < A.n_pixels)
+        A.planes[(size_t)plane * A.n_pixels + px] = 0.0f;
+    }
+  }
+}
+
+// The block's EndArgs, written by one lane before the block's first barrier and read back (as scalars) after the loop.
+__device__ __forceinline__ void park_end_args(const TraceArgs & A)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  EndArgs * const e = reinterpret_cast<EndArgs *>(lds_raw);
+  e->partial = A.partial;
+  e->planes = A.planes;
+  e->shared = A.shared;
+  e->n_pixels = A.n_pixels;
+  e->n_items = A.n_items;
+  e->queue_items = A.queue_items;
+  e->run_items = A.run_items;
+  e->run_stride = A.run_stride;
+  e->run_first = A.run_first;
+  e->s_row = A.s_row;
+  e->slice_count = A.slice_count;
+  e->share_depth = A.share_depth;
+  e->log_entries = min(A.log_entries, kLogEntries);
+}
+__device__ __forceinline__ EndArgs read_end_args()
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const uint32_t * const w = reinterpret_cast<const uint32_t *>(lds_raw);
+  uint32_t v[sizeof(EndArgs) / 4u];
+#pragma unroll
+  for (uint32_t k = 0; k < sizeof(EndArgs) / 4u; ++k)
+    v[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[k]);
+  EndArgs e;
+  __builtin_memcpy(&e, v, sizeof(e));
+  return e;
+}
+// rt_core.h queue_item for EndArgs
+__device__ __forceinline__ uint32_t end_queue_item(const EndArgs & E, uint32_t pos)
+{
+  if (E.run_items == 0u)
+    return pos;
+  uint32_t const run = pos / E.run_items;
+  return (run * E.run_stride + E.run_first) * E.run_items + (pos - run * E.run_items);
+}
+
+// The end of a wave in the kernels with kLog (see kLogEntries): fold pass and accumulate pass over the wave's own
+// columns.  log: the wave's log; entries: reservations it made; stage: LDS of the wave, room for kStageWindows
+// windows of column sums.  s_row divides the 64-item window, so a window holds whole pixels and starts at one.
+// The windows are read kGroupWindows at a time (three loads per lane and window, all in flight together: the wave
+// pays the memory's latency once per group, and it has the registers now), then summed kStageWindows at a time.
+constexpr uint32_t kStageWindows = 2;
+constexpr uint32_t kGroupWindows = 8;
+constexpr uint32_t kListWindows = 96;   // window positions the wave lists at a time (in the 128 words of the split table)
+static_assert(kListWindows % kGroupWindows == 0u && kGroupWindows % kStageWindows == 0u && kListWindows + 3u <= 128u, "");
+__device__ __forceinline__ float load_written(const float * p)
+{
+  // written earlier by this wave: read past the vector cache, which may hold an older copy of the line
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t listed(const uint32_t * list, uint32_t k, uint32_t n)
+{
+  return k < n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)list[k]) : RT_INVALID;
+}
+// Pixel sums of the windows in `stage` (list[first .. first + kStageWindows), as far as the list goes): the accumulate
+// pass of each pixel and plane, 0 + column 0 + column 1 + ... as colsum_kernel adds them.
+template <uint32_t kS>
+__device__ __forceinline__ void sum_stage(const EndArgs & E, const float * stage, const uint32_t * list, uint32_t first, uint32_t n,
+                                          uint32_t lane)
+{
+  constexpr uint32_t kChains = 3u * (kItemBatch / kS);  // sums of a window: a pixel's red, green, blue
+  for (uint32_t c = lane; c < kStageWindows * kChains; c += 64u)
+  {
+    uint32_t const k = c / kChains, r = c - k * kChains;
+    uint32_t const pixel = r / 3u, plane = r - 3u * pixel;
+    if (first + k < n)
+    {
+      uint32_t const at = list[first + k];
+      if (at < E.queue_items && pixel * kS < E.queue_items - at)
+      {
+        const float * v = stage + k * 3u * kItemBatch + 3u * pixel * kS + plane;
+        float sum = 0.0f;
+#pragma unroll 16
+        for (uint32_t i = 0; i < kS; ++i)
+          sum += v[3u * i];
+        size_t const px = (size_t)(end_queue_item(E, at) / kS) + pixel;
+        if (px < E.n_pixels)
+          E.planes[(size_t)plane * E.n_pixels + px] = sum;
+      }
+    }
+  }
+}
+// The listed windows, kGroupWindows at a time: three loads per lane and window, all in flight together (64
+// consecutive floats per load instruction), then summed kStageWindows at a time.
+template <uint32_t kS>
+__device__ __forceinline__ void sum_windows(const EndArgs & E, const uint32_t * list, uint32_t n, float * stage, uint32_t lane)
+{
+  for (uint32_t g = 0; g < n; g += kGroupWindows)
+  {
+    float v[kGroupWindows][3];
+#pragma unroll
+    for (uint32_t k = 0; k < kGroupWindows; ++k)
+    {
+      uint32_t const pos = listed(list, g + k, n);
+#pragma unroll
+      for (uint32_t j = 0; j < 3u; ++j)
+        v[k][j] = 0.0f;
+      if (pos < E.queue_items)
+      {
+        uint32_t const floats = 3u * min(kItemBatch, E.queue_items - pos);
+        const float * const src = E.partial + 3u * (size_t)end_queue_item(E, pos);
+#pragma unroll
+        for (uint32_t j = 0; j < 3u; ++j)
+          if (lane + 64u * j < floats)
+            v[k][j] = load_written(src + lane + 64u * j);
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kGroupWindows; k += kStageWindows)
+    {
+      if (g + k < n)
+      {
+#pragma unroll
+        for (uint32_t q = 0; q < kStageWindows; ++q)
+#pragma unroll
+          for (uint32_t j = 0; j < 3u; ++j)
+            stage[q * 3u * kItemBatch + lane + 64u * j] = v[k + q][j];
+        wave_fence();
+        sum_stage<kS>(E, stage, list, g + k, n, lane);
+        wave_fence();
+      }
+    }
+  }
+}
+__device__ __forceinline__ void wave_sums(uint32_t * log, uint32_t entries, float * stage)
+{
+  EndArgs const E = read_end_args();
+  uint32_t const lane = __lane_id();
+  // every column sum and shared colour of this wave is in memory
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  {
+    uint32_t const slot = log[kLogEntries + 2u * lane], first = log[kLogEntries + 2u * lane + 1u];
+    if (slot != RT_INVALID && slot < E.n_items)
+    {
+      // rt_core.h fold_split: the owner's part, then the shared colours in increasing sy
+      float * const c = E.partial + 3u * (size_t)slot;
+      f3 sum = mk3(load_written(c), load_written(c + 1), load_written(c + 2));
+      size_t const base = (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * E.share_depth;
+      for (uint32_t sy = first; sy < E.s_row; sy += E.slice_count)
+      {
+        const float * const v = E.shared + 3u * (base + (E.s_row - 1u - sy));
+        sum = sum + mk3(load_written(v), load_written(v + 1), load_written(v + 2));
+      }
+      store3(c, sum);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  wave_fence();
+  uint32_t * const list = log + kLogEntries;  // the split table has done its work
+  uint32_t e = 0, w = 0;                      // the next window to list: entry, window of it
+  for (;;)
+  {
+    if (lane == 0u)
+    {
+      uint32_t n = 0;
+      while (e < entries && n < kListWindows)
+      {
+        uint32_t const rec = log[e];
+        uint32_t const first_pos = rec & ~(kItemBatch - 1u), windows = (rec & (kItemBatch - 1u)) + 1u;
+        for (; w < windows && n < kListWindows; ++w)
+          if (first_pos + w * kItemBatch < E.queue_items)
+            list[n++] = first_pos + w * kItemBatch;
+        if (w == windows)
+        {
+          e += 1u;
+          w = 0u;
+        }
+      }
+      list[kListWindows] = n;
+      list[kListWindows + 1u] = e;
+      list[kListWindows + 2u] = w;
+    }
+    wave_fence();
+    uint32_t const n = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[kListWindows]);
+    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[kListWindows + 1u]);
+    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[kListWindows + 2u]);
+    if (n == 0u)
+      break;
+    switch (E.s_row)
+    {
+    case 1: sum_windows<1>(E, list, n, stage, lane); break;
+    case 2: sum_windows<2>(E, list, n, stage, lane); break;
+    case 4: sum_windows<4>(E, list, n, stage, lane); break;
+    case 8: sum_windows<8>(E, list, n, stage, lane); break;
+    case 16: sum_windows<16>(E, list, n, stage, lane); break;
+    case 32: sum_windows<32>(E, list, n, stage, lane); break;
+    default: sum_windows<64>(E, list, n, stage, lane); break;
+    }
+    wave_fence();
+  }
+}
+
 // LDS layout: [path stacks, unless kForward][jitter table][resident: filter, camera table, exact records, materials, lights,
 // prepared-column tables | tiled: one staging tile].
 // kLibMath: see rt_core.h Env::kLibraryMath (only the kernels for any number of lights come in that form).
 // kFused: the kernel takes the pixel sums itself (PixelRing; only the kForward kernels with the short exact sequences
 // come in that form).
-template <bool kTiled, bool kForward, bool kOneLight, bool kLibMath = false, bool kFused = false>
+// kLog: the waves take the pixel sums when they have no more work (wave_sums; resident layout only, not with kFused).
+template <bool kTiled, bool kForward, bool kOneLight, bool kLibMath = false, bool kFused = false, bool kLog = false>
 __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForward : (kTiled && kForward ? RT_TILED_WAVES : kWavesPerSimd)) void trace_kernel(TraceArgs A)
 {
+  static_assert(!kLog || (!kTiled && !kFused), "the reservation log belongs to the resident layout");
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  f4 * stack = reinterpret_cast<f4 *>(lds_raw);                    // [RT_MAX_DEPTH][kBlock]
+  f4 * stack = reinterpret_cast<f4 *>(lds_raw + (kLog ? kLogBlockBytes : 0u));  // [RT_MAX_DEPTH][kBlock]
   f4 * sph = stack + (kForward ? 0u : RT_MAX_DEPTH * kBlock);      // resident scene, or the staging tile
   LaneCounters cnt = {};
 #if defined(RT_PROFILE_REGIONS)
@@ -922,16 +1210,25 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
       smat[i] = A.sphere_mat[i];
       aux[i] = kOneLight ? A.aux_cone[i] : A.aux_rw[i];
     }
+    if constexpr (kLog)
+    {
+      wave_log()[kLogEntries + 2u * __lane_id()] = RT_INVALID;  // no column with shared samples yet
+      if (threadIdx.x == 0u)
+        park_end_args(A);
+      zero_other_runs(A);
+    }
     __syncthreads();
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
-    WaveEnv<kLibMath, kFused> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + wave_in_block() * kItemBatch, ItemPool(), PixelRing()};
+    WaveEnv<kLibMath, kFused, kLog> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + wave_in_block() * kItemBatch, ItemPool(), PixelRing()};
     if constexpr (kFused)
       env.ring.init(A, reinterpret_cast<unsigned char *>(batch + (kBlock / 64u) * kItemBatch) + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
     if constexpr (kFused)
       env.ring.drain(A);
+    if constexpr (kLog)
+      wave_sums(wave_log(), min(env.pool.refills, min(A.log_entries, kLogEntries)), reinterpret_cast<float *>(env.batch));
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(2);
 #endif
@@ -1253,6 +1550,7 @@ struct rt_hip_scene
     bool tiled = false;
     int per_cu = 0;
     uint32_t ring_slots = 0;
+    bool log_fits = false;    // the waves' reservation logs fit beside the rest without costing a block per compute unit
   };
   mutable Occupancy occupancy[4];
   mutable std::mutex occupancy_mutex;
@@ -1359,8 +1657,9 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags, uint32_t ring_slots)
 
 // The kernel for a scene: resident / tiled / grid walk, stack or forward accumulation; the forward kernels of
 // the resident and the grid path also come specialised for scenes with exactly one light.
+// wave_sums: the kernel whose waves take the pixel sums when they run out of work (resident layout, not with `fused`).
 template <class Launch>
-auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_math, bool fused, Launch && go)
+auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_math, bool fused, bool wave_sums, Launch && go)
 {
   bool const one = sc->n_lights == 1u;
   if (library_math)
@@ -1371,6 +1670,8 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_mat
       return sc->forward_ok ? go(trace_kernel_grid<true, false, true>) : go(trace_kernel_grid<false, false, true>);
     if (is_tiled(sc))
       return sc->forward_ok ? go(trace_kernel<true, true, false, true>) : go(trace_kernel<true, false, false, true>);
+    if (wave_sums)
+      return sc->forward_ok ? go(trace_kernel<false, true, false, true, false, true>) : go(trace_kernel<false, false, false, true, false, true>);
     return sc->forward_ok ? go(trace_kernel<false, true, false, true>) : go(trace_kernel<false, false, false, true>);
   }
   if (uses_grid(sc, flags))
@@ -1390,9 +1691,11 @@ auto with_trace_kernel(const rt_hip_scene * sc, uint32_t flags, bool library_mat
     return one ? go(trace_kernel<true, true, true>) : go(trace_kernel<true, true, false>);
   }
   if (!sc->forward_ok)
-    return go(trace_kernel<false, false, false>);
+    return wave_sums ? go(trace_kernel<false, false, false, false, false, true>) : go(trace_kernel<false, false, false>);
   if (fused)
     return one ? go(trace_kernel<false, true, true, false, true>) : go(trace_kernel<false, true, false, false, true>);
+  if (wave_sums)
+    return one ? go(trace_kernel<false, true, true, false, false, true>) : go(trace_kernel<false, true, false, false, false, true>);
   return one ? go(trace_kernel<false, true, true>) : go(trace_kernel<false, true, false>);
 }
 
@@ -1431,9 +1734,9 @@ rt_hip_scene::Occupancy launch_shape(const rt_hip_scene * sc, uint32_t flags, bo
   rt_hip_scene::Occupancy & cached = sc->occupancy[(uses_grid(sc, flags) ? 1 : 0) + (library_math ? 2 : 0)];
   if (cached.lds != lds || cached.tiled != is_tiled(sc) || cached.per_cu < 1)
   {
-    auto blocks_with = [&](size_t bytes, bool fused) {
+    auto blocks_with = [&](size_t bytes, bool fused, bool wave_sums = false) {
       int asked = 0;
-      hipError_t const e = with_trace_kernel(sc, flags, library_math, fused, [&](auto kernel) {
+      hipError_t const e = with_trace_kernel(sc, flags, library_math, fused, wave_sums, [&](auto kernel) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked, kernel, kBlock, bytes);
       });
       return (e != hipSuccess || asked < 1) ? 0 : asked;
@@ -1441,6 +1744,8 @@ rt_hip_scene::Occupancy launch_shape(const rt_hip_scene * sc, uint32_t flags, bo
     cached.lds = lds;
     cached.tiled = is_tiled(sc);
     cached.per_cu = std::max(blocks_with(lds, false), 1);
+    cached.log_fits = !cached.tiled && !uses_grid(sc, flags) && lds + kLogBlockBytes <= g_lib.lds_per_block &&
+                      blocks_with(lds + kLogBlockBytes, false, true) >= cached.per_cu;
     cached.ring_slots = 0u;
     for (uint32_t slots = kRingMaxSlots; has_fused_kernel(sc, library_math) && slots >= kRingMinSlots; --slots)
     {
@@ -1591,6 +1896,7 @@ struct TraceTarget
   bool clear_first = false;     // a job: what snapshots read (pixel sums, or column sums) starts from zero
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // recorded directly around the trace kernel (and its fold pass)
   bool fused = false;           // out: the kernel took the pixel sums itself
+  bool wave_sums = false;       // out: the kernel left column sums and its waves added them up as they ended
 };
 
 // Enqueues, on `stream`: the set-up kernel (camera table for this frame's camera, counters reset), the trace kernel and
@@ -1674,7 +1980,45 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   int const blocks = persistent_blocks(scene, p->flags, library_math, std::max<uint32_t>(a.queue_items, 1u),
                                        (unsigned long long)a.queue_items * per_column, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
-  size_t const lds = lds_bytes(scene, p->flags, a.ring_slots);
+  // Pixel sums by the waves as they end (kLogEntries): the resident kernels, when a window holds whole pixels and the
+  // waves' logs can hold the launch's reservations.  A wave makes its share of the reservations and a few dozen
+  // shrinking ones at the end of the queue; four times the average has to fit its log, so frames of many windows get
+  // longer reservations.  And however the waves divide the queue, the logs together hold every reservation it can be
+  // cut into (each takes batch_min positions or more; one may be clipped by the end of the queue, one per wave
+  // lies past it).  RT_HIP_NO_WAVE_SUMS (any value): off, for comparisons.
+  // Only launches that fill the chip: beside a smaller grid (small frames, persistent_blocks) the passes find free
+  // block slots and cost a stream of frames nothing, while the waves' own sums lengthen every wave a little.
+  // RT_HIP_LOG_ENTRIES=n (tests): the waves' logs take n reservations, and the launch goes ahead whatever the grid.
+  t.wave_sums = false;
+  uint32_t log_entries = kLogEntries;
+  bool forced = false;
+  if (const char * v = std::getenv("RT_HIP_LOG_ENTRIES"))
+  {
+    log_entries = std::min<uint32_t>(kLogEntries, std::max<uint32_t>(2u, (uint32_t)std::strtoul(v, nullptr, 10)));
+    forced = true;
+  }
+  rt_hip_scene::Occupancy const shape = launch_shape(scene, p->flags, library_math);
+  bool const full_grid = blocks >= shape.per_cu * std::max(g_lib.compute_units, 1) - kSnapshotReserveBlocks;
+  if (!t.fused && t.work != nullptr && a.s_row <= kItemBatch && (kItemBatch % a.s_row) == 0u && a.queue_items != 0u &&
+      shape.log_fits && (full_grid || forced) && std::getenv("RT_HIP_NO_WAVE_SUMS") == nullptr)
+  {
+    unsigned long long const waves = a.guide_waves;
+    unsigned long long const windows = ((unsigned long long)a.queue_items + kItemBatch - 1u) / kItemBatch;
+    unsigned long long const room = forced ? windows : log_entries - 64u;
+    unsigned long long const batch_windows =
+        std::max<unsigned long long>(a.batch_items / kItemBatch, (4u * windows + waves * room - 1u) / (waves * room));
+    unsigned long long const hold = log_entries - 1u;  // (a wave's last reservation lies past the end of the queue)
+    unsigned long long const min_windows =
+        std::max<unsigned long long>(a.batch_min / kItemBatch, (windows + waves * hold - 1u) / (waves * hold) + (forced ? 1u : 0u));
+    if (batch_windows <= kLogMaxWindows && min_windows <= kLogMaxWindows)
+    {
+      a.batch_items = (uint32_t)std::max(batch_windows, min_windows) * kItemBatch;
+      a.batch_min = (uint32_t)min_windows * kItemBatch;
+      a.log_entries = log_entries;
+      t.wave_sums = true;
+    }
+  }
+  size_t const lds = lds_bytes(scene, p->flags, a.ring_slots) + (t.wave_sums ? kLogBlockBytes : 0u);
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
   size_t const lanes = (size_t)blocks * kBlock;
   size_t const share_at = share_offset(p, t.fused);
@@ -1691,12 +2035,21 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   // writes its own pixels only) and whatever a snapshot may read before the kernel has written it.
   if (t.fused && (t.clear_first || pixel_runs(p)))
     RT_CHECK(hipMemsetAsync(t.planes, 0, 3 * sizeof(float) * (size_t)a.n_pixels, stream));
+  auto zero_floats = [&](float * at, size_t floats) {
+    int const fill_blocks = (int)std::min<size_t>((floats / 4u + 255u) / 256u + 1u, 256u * 8u);
+    hipLaunchKernelGGL(zero_kernel, dim3(fill_blocks), dim3(256), 0, stream, at, floats);
+  };
   if (!t.fused && t.clear_first)
   {
-    size_t const floats = partial_bytes(p) / sizeof(float);
-    int const fill_blocks = (int)std::min<size_t>((floats / 4u + 255u) / 256u + 1u, 256u * 8u);
-    hipLaunchKernelGGL(zero_kernel, dim3(fill_blocks), dim3(256), 0, stream, t.work, floats);
+    zero_floats(t.work, partial_bytes(p) / sizeof(float));
     RT_CHECK(hipGetLastError());
+    // (a job may be cancelled: the pixels of windows no wave reserved keep the zero sums the accumulate pass would
+    // have given them)
+    if (t.wave_sums)
+    {
+      zero_floats(t.planes, 3u * (size_t)a.n_pixels);
+      RT_CHECK(hipGetLastError());
+    }
   }
   {
     int const tab_blocks = std::max(1, (int)((scene->n_padded + 255u) / 256u));
@@ -1706,12 +2059,12 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   if (t.ev_start)
     RT_CHECK(hipEventRecord(t.ev_start, stream));
-  (void)with_trace_kernel(scene, p->flags, library_math, t.fused, [&](auto kernel) {
+  (void)with_trace_kernel(scene, p->flags, library_math, t.fused, t.wave_sums, [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, stream, a);
     return hipSuccess;
   });
   RT_CHECK(hipGetLastError());
-  if (!t.fused && a.share_depth != 0u)
+  if (!t.fused && !t.wave_sums && a.share_depth != 0u)
   {
     hipLaunchKernelGGL(fold_kernel, dim3(std::min(blocks, 256)), dim3(256), 0, stream, t.work, a.shared, a.splits,
                        a.split_count, a.s_row, a.slice_count);
@@ -1719,7 +2072,7 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   if (t.ev_stop)
     RT_CHECK(hipEventRecord(t.ev_stop, stream));
-  if (!t.fused)
+  if (!t.fused && !t.wave_sums)
     return launch_colsum(t.work, t.planes, p, stream);
   return RT_HIP_OK;
 }
