@@ -62,8 +62,10 @@ extern "C" {
                                         (scenes of 64 spheres or more; ignored for smaller ones).  Same image: the
                                         grid only selects which spheres the exact intersection is run on. */
 #define RT_HIP_FLAG_PIPELINED 4u     /* the frame is one of a stream of frames traced on alternating streams
-                                        (rt_hip_trace_device).  A hint: accepted, and at present without effect (it
-                                        used to keep the launch's work reservations large to the end).  Same image. */
+                                        (rt_hip_trace_device), whose first waves take over the compute units this
+                                        frame's last waves leave.  A hint: the launch then keeps its last work
+                                        reservations at two queue windows instead of one, which serves the stream's
+                                        throughput and costs a frame traced on its own a little.  Same image. */
 
 #define RT_HIP_FLAG_LEAVE_ROOM 8u    /* the launch leaves 64 of the chip's block slots (of 1024) free, so that another
                                         kernel -- the RCCL reduce of the previous frame on a multi-GPU driver -- finds

@@ -1822,12 +1822,17 @@ uint32_t batch_items(unsigned long long items, unsigned long long per_column, in
 }
 
 // Smallest reservation near the end of the queue: about 256 samples' worth (the counter word stays well below
-// its limit even if every reservation were that small), at least one window (two where a sample costs little).
-uint32_t batch_min(unsigned long long per_column, uint32_t batch, unsigned long long cost)
+// its limit even if every reservation were that small), at least one window.  A frame in a stream of frames
+// (`pipelined`, RT_HIP_FLAG_PIPELINED) takes at least two where a sample costs little: the next frame's waves fill the
+// chip as this frame's leave, so the end of the launch costs little, and single windows cost more in atomics and in
+// neighbouring pixels lost than they gain (1/8 of the 1080p 16x16 frame in a stream: 2.42 ms against 2.49).  A frame
+// traced on its own ends when its last wave does, and single windows end it sooner where a window is 1024 samples or
+// more (16x16: 17.9 -> 17.3 ms, 1/8 of it 3.6 -> 3.0, 32x32 at 1024x768 26.5 -> 26.4; 10x10: 3.03 -> 3.14, so not there).
+uint32_t batch_min(unsigned long long per_column, uint32_t batch, unsigned long long cost, bool pipelined)
 {
   unsigned long long k = std::max<unsigned long long>(1u, (256u / cost + kItemBatch * per_column - 1u) / (kItemBatch * per_column));
-  if (cost == 1u)
-    k = std::max<unsigned long long>(k, 2u);  // single windows cost more in atomics than they gain in balance
+  if (cost == 1u && (pipelined || kItemBatch * per_column < 1024u))
+    k = std::max<unsigned long long>(k, 2u);
   return (uint32_t)std::min<unsigned long long>(k * kItemBatch, batch);
 }
 
@@ -1948,8 +1953,9 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     a.batch_items = std::max<uint32_t>(kItemBatch, (uint32_t)std::strtoul(v, nullptr, 10) / kItemBatch * kItemBatch);
   // (RT_HIP_FLAG_PIPELINED once kept the reservations of a frame in a stream of frames large to the end; since
   // reservations are four windows, shrinking them at the end is better there too: 17.64 -> 17.50 ms per 1080p 16x16
-  // frame, 2.93 -> 2.62 ms per 1/8 of one, 337 -> 329 ms per 3840x2160 32x32 frame.  The flag is accepted and ignored.)
-  a.batch_min = batch_min(per_column, a.batch_items, cost);
+  // frame, 2.93 -> 2.62 ms per 1/8 of one, 337 -> 329 ms per 3840x2160 32x32 frame.  What the flag still decides is
+  // how small the last reservations get.)
+  a.batch_min = batch_min(per_column, a.batch_items, cost, (p->flags & RT_HIP_FLAG_PIPELINED) != 0u);
   if (const char * v = std::getenv("RT_HIP_BATCH_MIN"))  // experiments: smallest reservation in items
     a.batch_min = std::min(a.batch_items, std::max<uint32_t>(kItemBatch, (uint32_t)std::strtoul(v, nullptr, 10) / kItemBatch * kItemBatch));
 

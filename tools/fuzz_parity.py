@@ -1,5 +1,5 @@
 """Random small frames through the HIP backend against the oracle: sizes, samples per row, slices, flags and
-scenes drawn at random.  Deterministic frames must match the oracle per pixel (1e-4 relative) with equal query
+scenes drawn at random.  Deterministic frames must match the oracle per pixel (1e-4 relative; 3e-4 above 64 samples per row) with equal query
 counters; stochastic frames must not change a bit when sample sharing is switched off, RT_HIP_FLAG_PIPELINED is set
 or the shadow cones are switched off (scenes with several lights of any length included), and the images of a
 frame's slices by runs of pixels must add up to the frame's image bit for bit.
@@ -137,7 +137,12 @@ while time.time() < t_end:
     cases += 1
     if cases % 50 == 0:
         print("%d cases so far, worst deterministic error %.3g" % (cases, worst), flush=True)
-    if err >= 1e-4 or not same or not stable or not np.isfinite(out).all():
+    # The oracle adds a pixel's s x s samples in one running float sum (ray_tracing/frame.cpp:55-67), the kernel as s
+    # column sums of s samples.  Over a constant region (sky) the long chain rounds the same way at every step, so the
+    # two drift apart with the sample count: 8.8e-5 at 70 x 70 on most scenes, 1.3e-4 on some.  The bar of 1e-4 is for
+    # the sample counts the reference uses (2, 10, 16, 32); above 64 the check is looser.
+    bar = 1e-4 if s <= 64 else 3e-4
+    if err >= bar or not same or not stable or not np.isfinite(out).all():
         print("FAILED: scene %d %dx%d s=%d slice %d/%d depth %d grid %d seed %d: err %.3g counters %s stable %s" % (
             si, w, h, s, idx, g, depth, grid, seed, err, same, stable))
         r.close()

@@ -96,12 +96,14 @@ if not quick:
                 r.trace_device(scene, p, planes[0].data_ptr(), None, stream)
             torch.cuda.synchronize()
             call_ms = (time.perf_counter() - t0) / 10 * 1e3
+            q = type(p).from_buffer_copy(p)
+            q.flags |= ffi.FLAG_PIPELINED  # one of a stream of frames
             for k in range(4):
-                r.trace_device(scene, p, planes[k % 2].data_ptr(), None, streams[k % 2].cuda_stream)
+                r.trace_device(scene, q, planes[k % 2].data_ptr(), None, streams[k % 2].cuda_stream)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(16):
-                r.trace_device(scene, p, planes[k % 2].data_ptr(), None, streams[k % 2].cuda_stream)
+                r.trace_device(scene, q, planes[k % 2].data_ptr(), None, streams[k % 2].cuda_stream)
             torch.cuda.synchronize()
             stream_ms = (time.perf_counter() - t0) / 16 * 1e3
             print("%-44s %-10s trace kernel (+ fold) %.3f ms, call %.3f ms, in a stream of frames %.3f ms" % (
