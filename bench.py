@@ -434,7 +434,10 @@ def main():
               ("_grid" if args.grid else "")
         prof = profiled(key)
         traffic = prof.get("trace_kernel_bytes_per_launch")
-        column_bytes = 12 * w * h * s  # what the algorithm writes to HBM: one column sum per sub-sample column
+        # what the kernel's algorithm moves through HBM: one column sum (12 B) written per sub-sample column; where the
+        # kernel's waves add up their own pixels as they end, they read those sums back and write 12 B per pixel
+        plan = renderer.describe(scene, p_alone)
+        column_bytes = 12 * w * h * s * (2 if plan.wave_sums else 1) // (world if by_runs else 1) + (12 * w * h if plan.wave_sums else 0)
         # vector instructions the kernel issued: counted by SQ_INSTS_VALU (64 lanes each) when this workload has a
         # committed counter profile, else modelled from this run's device counters
         lane_ops = executed_lane_ops(k, scene.sphere_count, args.grid, scene.sphere_count <= 64)
@@ -525,6 +528,10 @@ def main():
                 "max_depth": 10,
                 "intersection": "uniform grid" if args.grid else "every sphere (LDS-resident or LDS-tiled)",
                 "frames_in_flight": lanes,
+                "pixel_sums": ("by the trace kernel's waves as they run out of work" if plan.wave_sums else
+                               "inside the trace kernel's loop" if plan.kernel_sums else "fold and accumulate passes after the trace kernel"),
+                "launch": {"blocks": plan.blocks, "lds_bytes_per_block": plan.lds_bytes, "batch_items": plan.batch_items,
+                           "batch_min": plan.batch_min},
                 "collective": collective,
             },
             "value_note": "throughput of a stream of frames, %d in flight, images left in HBM; the latency of one frame "

@@ -251,6 +251,30 @@ int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * c
                              const rt_hip_trace_params * params, uint32_t launches, float * out_avg_ms,
                              rt_hip_stats * out_stats);
 
+/* No counterpart in the reference: how the library would trace a frame -- which kernel, how many blocks, how the
+ * pixel sums are taken -- without tracing it.  For tests and benchmarks, which want to know that the path they mean to
+ * measure is the one that runs; the answer is that of rt_hip_trace_device with a workspace of its own choosing. */
+typedef struct
+{
+  uint32_t blocks;        /* persistent blocks of 256 threads in the launch */
+  uint32_t lds_bytes;     /* dynamic LDS per block */
+  uint32_t batch_items;   /* queue positions (sub-sample columns) a wave reserves at a time ... */
+  uint32_t batch_min;     /* ... and near the end of the queue */
+  uint32_t tiled;         /* the scene is staged through LDS in tiles (else: resident in LDS, or walked on the grid) */
+  uint32_t grid;          /* rays walk the uniform grid (RT_HIP_FLAG_GRID on a scene that has one) */
+  uint32_t forward;       /* path colours accumulated forward (else the reference's reverse loop over a stack) */
+  uint32_t one_light;     /* kernel specialised for one light */
+  uint32_t library_math;  /* kernel built with the compiler's IEEE square root and division */
+  uint32_t column_masks;  /* primary rays filtered once per sub-sample column */
+  uint32_t sample_sharing;/* idle lanes take samples of busy lanes' columns at the end of the queue */
+  uint32_t kernel_sums;   /* pixel sums taken inside the kernel's loop (RT_HIP_FLAG_KERNEL_SUMS) */
+  uint32_t wave_sums;     /* pixel sums taken by the kernel's waves as they run out of work; neither: the fold and
+                             accumulate passes follow the kernel */
+  uint32_t reserved[3];
+} rt_hip_launch_info;
+int rt_hip_describe_launch(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                           const rt_hip_trace_params * params, rt_hip_launch_info * out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1902,6 +1902,7 @@ struct TraceTarget
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // recorded directly around the trace kernel (and its fold pass)
   bool fused = false;           // out: the kernel took the pixel sums itself
   bool wave_sums = false;       // out: the kernel left column sums and its waves added them up as they ended
+  rt_hip_launch_info * describe = nullptr;  // not null: nothing is enqueued, the launch is described here instead
 };
 
 // Enqueues, on `stream`: the set-up kernel (camera table for this frame's camera, counters reset), the trace kernel and
@@ -2036,6 +2037,25 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
     a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
     a.shared_off = (size_t)(a.shared - t.work);
     a.share_depth = share_depth(p);
+  }
+  if (t.describe != nullptr)
+  {
+    rt_hip_launch_info & d = *t.describe;
+    std::memset(&d, 0, sizeof(d));
+    d.blocks = (uint32_t)blocks;
+    d.lds_bytes = (uint32_t)lds;
+    d.batch_items = a.batch_items;
+    d.batch_min = a.batch_min;
+    d.grid = uses_grid(scene, p->flags) ? 1u : 0u;
+    d.tiled = (!d.grid && is_tiled(scene)) ? 1u : 0u;
+    d.forward = scene->forward_ok ? 1u : 0u;
+    d.library_math = library_math ? 1u : 0u;
+    d.one_light = (scene->n_lights == 1u && scene->forward_ok && !library_math) ? 1u : 0u;
+    d.column_masks = a.column_masks;
+    d.sample_sharing = a.share_depth != 0u ? 1u : 0u;
+    d.kernel_sums = t.fused ? 1u : 0u;
+    d.wave_sums = t.wave_sums ? 1u : 0u;
+    return RT_HIP_OK;
   }
   // What must start from zero: the sums of the pixels this slice does not trace (slices by runs of pixels: the kernel
   // writes its own pixels only) and whatever a snapshot may read before the kernel has written it.
@@ -2806,6 +2826,23 @@ int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t wi
   if (d_sum_planes == nullptr || d_rgb == nullptr || width == 0 || height == 0 || samples_in_row == 0)
     return fail(RT_HIP_ERR_INVALID, "bad argument");
   return launch_resolve(d_sum_planes, d_rgb, width, height, samples_in_row, static_cast<hipStream_t>(stream));
+}
+
+int rt_hip_describe_launch(const rt_hip_scene * scene, const rt_hip_camera * camera,
+                           const rt_hip_trace_params * params, rt_hip_launch_info * out)
+{
+  int const rc = validate(scene, camera, params);
+  if (rc != RT_HIP_OK)
+    return rc;
+  if (out == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
+  TraceTarget t;
+  // (nothing is read or written through these: a workspace of the size rt_hip_trace_device would bring)
+  t.work = reinterpret_cast<float *>(static_cast<uintptr_t>(256));
+  t.work_bytes = trace_buffer_bytes(params, fused);
+  t.describe = out;
+  return launch_trace(scene, camera, params, t, nullptr);
 }
 
 int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * camera,

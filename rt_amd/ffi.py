@@ -56,6 +56,17 @@ class HostHit(C.Structure):
     _fields_ = [("t", C.c_float), ("position", C.c_float * 3), ("normal", C.c_float * 3), ("sphere", C.c_uint32)]
 
 
+class LaunchInfo(C.Structure):
+    """rt_hip_launch_info: how the library would trace a frame (rt_hip_describe_launch)."""
+
+    _fields_ = [(name, C.c_uint32) for name in (
+        "blocks", "lds_bytes", "batch_items", "batch_min", "tiled", "grid", "forward", "one_light", "library_math",
+        "column_masks", "sample_sharing", "kernel_sums", "wave_sums")] + [("reserved", C.c_uint32 * 3)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64),
@@ -117,6 +128,7 @@ HIP_SYMBOLS = {
         [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(Stats)],
     ),
     "rt_hip_check_exact_math": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "rt_hip_describe_launch": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.POINTER(LaunchInfo)]),
 }
 
 HOST_SYMBOLS = {
@@ -369,6 +381,13 @@ class HipRenderer:
             "rt_hip_time_trace_kernel",
         )
         return ms.value, stats
+
+    def describe(self, scene, p):
+        """How the library would trace this frame: a LaunchInfo (nothing is traced)."""
+        info = LaunchInfo()
+        self._check(self.lib.rt_hip_describe_launch(self.upload(scene), C.byref(scene.camera), C.byref(p), C.byref(info)),
+                    "rt_hip_describe_launch")
+        return info
 
     def check_exact_math(self):
         """Mismatch counts of the device self-check of the short correctly rounded sqrt / quotient sequences."""

@@ -30,7 +30,7 @@ CASES = [
     (2, 0, 200, 120, 8, 0, (1, 3, False)),       # slice by samples: every third sample of every column
     (1, 0, 333, 200, 16, 0, (2, 8, True)),       # slice by runs of 64 pixels
     (1, 0, 31, 17, 32, 0, (5, 7, True)),         # more slices than some of them have runs
-    (3, 200, 320, 240, 4, 0, None),              # 201 spheres: resident, primary rays filtered per sample
+    (3, 100, 320, 240, 4, 0, None),              # 101 spheres: resident, primary rays filtered per sample
     (3, 200, 320, 240, 4, "grid", None),         # the same through the uniform grid
     (3, 3000, 160, 120, 2, 0, None),             # LDS tiles: the block's waves move in step
     (1, 0, 1024, 768, 2, 0, None),               # the reference's default window
@@ -47,6 +47,9 @@ def test_kernel_sums_change_no_bit(hip, ffi, scenes, case):
     fl = ffi.FLAG_GRID if flags == "grid" else 0
     make = lambda: ffi.params(w, h, s, seed=5, flags=fl)  # noqa: E731
     p = sharding.slice_params(make, sl[0], sl[1], pixel_runs=sl[2]) if sl else make()
+    with_flag = type(p).from_buffer_copy(p)
+    with_flag.flags |= ffi.FLAG_KERNEL_SUMS
+    assert hip.describe(scene, with_flag).kernel_sums == 1 and hip.describe(scene, p).kernel_sums == 0
     a, sa = planes_and_counters(hip, ffi, scene, p, True)
     b, sb = planes_and_counters(hip, ffi, scene, p, False)
     assert sa[10] == 0 and sb[10] == 0  # no wave gave up waiting for a window slot
@@ -58,6 +61,7 @@ def test_kernel_sums_ignored_where_a_window_holds_no_whole_pixels(hip, ffi, scen
     """10 samples per row (the viewer's high-quality mode): the flag is accepted and the frame is traced as without."""
     scene = scenes(2)
     p = ffi.params(120, 90, 10, seed=3)
+    assert hip.describe(scene, ffi.params(120, 90, 10, seed=3, flags=ffi.FLAG_KERNEL_SUMS)).kernel_sums == 0
     a, sa = planes_and_counters(hip, ffi, scene, p, True)
     b, sb = planes_and_counters(hip, ffi, scene, p, False)
     assert sa[:4] == sb[:4] and bool((a == b).all())

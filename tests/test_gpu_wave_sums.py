@@ -25,9 +25,11 @@ def both_ways(hip, scene, p, monkeypatch, log_entries="384"):
     monkeypatch.delenv("RT_HIP_NO_WAVE_SUMS", raising=False)
     if log_entries is not None:
         monkeypatch.setenv("RT_HIP_LOG_ENTRIES", log_entries)
+    assert hip.describe(scene, p).wave_sums == 1  # the path under test is the one that runs
     a, sa = planes_and_counters(hip, scene, p)
     monkeypatch.delenv("RT_HIP_LOG_ENTRIES", raising=False)
     monkeypatch.setenv("RT_HIP_NO_WAVE_SUMS", "1")
+    assert hip.describe(scene, p).wave_sums == 0
     b, sb = planes_and_counters(hip, scene, p)
     monkeypatch.delenv("RT_HIP_NO_WAVE_SUMS")
     return a, sa, b, sb
@@ -42,11 +44,11 @@ CASES = [
     (2, 0, 200, 120, 8, (1, 3, False), "384"),       # slice by samples: every third sample of every column
     (1, 0, 333, 200, 16, (2, 8, True), "384"),       # slice by runs of 64 pixels: the other runs' sums are zero
     (1, 0, 31, 17, 32, (5, 7, True), "384"),         # more slices than some of them have runs
-    (3, 200, 320, 240, 4, None, "384"),              # 201 spheres: resident, primary rays filtered per sample
+    (3, 100, 320, 240, 4, None, "384"),              # 101 spheres: resident, primary rays filtered per sample
     (1, 0, 640, 360, 16, None, "3"),                 # three reservations per wave: the logs fill up
     (2, 0, 320, 240, 8, (0, 2, True), "2"),
     (1, 0, 1024, 768, 2, None, "384"),               # the reference's default window
-    (2, 0, 640, 480, 16, None, None),                # as a caller gets it
+    (2, 0, 1280, 720, 16, None, None),               # as a caller gets it: the launch fills the chip
 ]
 
 
@@ -122,3 +124,28 @@ def test_wave_sums_through_the_job_api(hip, ffi, scenes, monkeypatch):
     hip.cancel(job)
     part, _ = hip.finish(job, big, allow_cancelled=True)
     assert ((part == 0.0) | (part == whole)).all()
+
+
+def test_which_frames_take_which_path(hip, ffi, scenes):
+    """rt_hip_describe_launch: the waves take the sums for launches that fill the chip and whose windows hold whole
+    pixels; small frames, sample counts that do not divide 64, tiled scenes and grid walks keep the passes."""
+    pretty = scenes(1)
+    headline = hip.describe(pretty, ffi.params(1920, 1080, 16))
+    assert (headline.wave_sums, headline.kernel_sums, headline.blocks, headline.forward, headline.one_light,
+            headline.column_masks, headline.sample_sharing) == (1, 0, 1024, 1, 1, 1, 1)
+    assert headline.batch_items == 256 and headline.batch_min == 64
+    stream = hip.describe(pretty, ffi.params(1920, 1080, 16, flags=ffi.FLAG_PIPELINED))
+    assert stream.batch_min == 128 and stream.wave_sums == 1
+    assert hip.describe(pretty, ffi.params(1024, 768, 2)).wave_sums == 0       # a third of the chip's block slots
+    assert hip.describe(scenes(2), ffi.params(1024, 768, 10)).wave_sums == 0   # 10 does not divide 64
+    fused = hip.describe(pretty, ffi.params(1920, 1080, 16, flags=ffi.FLAG_KERNEL_SUMS))
+    assert (fused.kernel_sums, fused.wave_sums) == (1, 0)
+    # 201 spheres with as many materials: resident, but the waves' logs would cost a block per compute unit
+    assert hip.describe(scenes(3, 1, 200), ffi.params(1920, 1080, 4)).wave_sums == 0
+    big = scenes(3, 1, 3000)
+    tiled = hip.describe(big, ffi.params(640, 360, 4))
+    assert (tiled.tiled, tiled.grid, tiled.wave_sums) == (1, 0, 0)
+    walked = hip.describe(big, ffi.params(640, 360, 4, flags=ffi.FLAG_GRID))
+    assert (walked.tiled, walked.grid, walked.wave_sums) == (0, 1, 0)
+    four_k = hip.describe(scenes(2), ffi.params(3840, 2160, 32))
+    assert four_k.wave_sums == 1 and four_k.batch_items >= 256  # long reservations: the waves' logs hold them
