@@ -78,6 +78,17 @@ def test_wave_sums_of_the_headline_frame_and_its_slices(hip, ffi, scenes, monkey
         assert bool((a == b).all())
 
 
+def test_wave_sums_of_the_largest_configuration(hip, ffi, scenes, monkeypatch):
+    """glass_spheres 3840x2160, 32x32 samples per pixel: 4 million queue windows, reservations of 14 windows so that
+    the waves' logs hold them."""
+    scene = scenes(2)
+    p = ffi.params(3840, 2160, 32, seed=2)
+    assert hip.describe(scene, p).batch_items > 256
+    a, sa, b, sb = both_ways(hip, scene, p, monkeypatch, None)
+    assert sa[0] == sb[0] == 3840 * 2160 * 32 * 32 and sa[:4] == sb[:4]
+    assert bool((a == b).all())
+
+
 def test_wave_sums_with_path_stacks_several_lights_and_library_math(hip, ffi, monkeypatch):
     """The other resident kernels: the reference's reverse loop over a stack (RT_HIP_FORCE_STACK), any number of
     lights, the compiler's IEEE sequences (RT_HIP_LIBRARY_MATH)."""
