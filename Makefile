@@ -56,7 +56,7 @@ tests/emu/libcore_emu.so: tests/emu/core_emu.cpp $(CORE_HDRS)
 # tests under them.  For the build container only: no GPU is involved (librt_host.so links the ordinary librt_hip.so,
 # which loads without one).  Python itself is not instrumented, so the sanitizer runtime is preloaded.
 #   make san        AddressSanitizer + UndefinedBehaviorSanitizer, then ThreadSanitizer
-SAN_TESTS := tests/test_oracle_golden.py tests/test_oracle_properties.py tests/test_emu_vs_oracle.py tests/test_host.py tests/test_sharding_runs.py
+SAN_TESTS := tests/test_oracle_golden.py tests/test_oracle_properties.py tests/test_emu_vs_oracle.py tests/test_host.py tests/test_sharding_runs.py tests/test_launch_plan.py
 SAN_HOST_SRC := rt_amd/host/rt_host_capi.cpp rt_amd/host/rt_hip/demo_frame_hip.cpp
 san: san-asan san-tsan
 

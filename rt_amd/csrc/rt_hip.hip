@@ -1988,14 +1988,11 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
                                        (unsigned long long)a.queue_items * per_column, leave_room);
   a.guide_waves = (uint32_t)blocks * (kBlock / 64u);
   // Pixel sums by the waves as they end (kLogEntries): the resident kernels, when a window holds whole pixels and the
-  // waves' logs can hold the launch's reservations.  A wave makes its share of the reservations and a few dozen
-  // shrinking ones at the end of the queue; four times the average has to fit its log, so frames of many windows get
-  // longer reservations.  And however the waves divide the queue, the logs together hold every reservation it can be
-  // cut into (each takes batch_min positions or more; one may be clipped by the end of the queue, one per wave
-  // lies past it).  RT_HIP_NO_WAVE_SUMS (any value): off, for comparisons.
+  // waves' logs can hold the launch's reservations (rt_prep.h plan_wave_logs sizes them).
   // Only launches that fill the chip: beside a smaller grid (small frames, persistent_blocks) the passes find free
   // block slots and cost a stream of frames nothing, while the waves' own sums lengthen every wave a little.
-  // RT_HIP_LOG_ENTRIES=n (tests): the waves' logs take n reservations, and the launch goes ahead whatever the grid.
+  // RT_HIP_NO_WAVE_SUMS (any value): off, for comparisons.  RT_HIP_LOG_ENTRIES=n (tests): the waves' logs take n
+  // reservations, and the launch goes ahead whatever the grid.
   t.wave_sums = false;
   uint32_t log_entries = kLogEntries;
   bool forced = false;
@@ -2009,18 +2006,12 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   if (!t.fused && t.work != nullptr && a.s_row <= kItemBatch && (kItemBatch % a.s_row) == 0u && a.queue_items != 0u &&
       shape.log_fits && (full_grid || forced) && std::getenv("RT_HIP_NO_WAVE_SUMS") == nullptr)
   {
-    unsigned long long const waves = a.guide_waves;
-    unsigned long long const windows = ((unsigned long long)a.queue_items + kItemBatch - 1u) / kItemBatch;
-    unsigned long long const room = forced ? windows : log_entries - 64u;
-    unsigned long long const batch_windows =
-        std::max<unsigned long long>(a.batch_items / kItemBatch, (4u * windows + waves * room - 1u) / (waves * room));
-    unsigned long long const hold = log_entries - 1u;  // (a wave's last reservation lies past the end of the queue)
-    unsigned long long const min_windows =
-        std::max<unsigned long long>(a.batch_min / kItemBatch, (windows + waves * hold - 1u) / (waves * hold) + (forced ? 1u : 0u));
-    if (batch_windows <= kLogMaxWindows && min_windows <= kLogMaxWindows)
+    LogPlan const plan = plan_wave_logs(a.queue_items, a.guide_waves, a.batch_items, a.batch_min, log_entries, forced,
+                                        kItemBatch, kLogMaxWindows);
+    if (plan.ok)
     {
-      a.batch_items = (uint32_t)std::max(batch_windows, min_windows) * kItemBatch;
-      a.batch_min = (uint32_t)min_windows * kItemBatch;
+      a.batch_items = plan.batch_items;
+      a.batch_min = plan.batch_min;
       a.log_entries = log_entries;
       t.wave_sums = true;
     }

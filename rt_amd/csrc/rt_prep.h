@@ -62,6 +62,47 @@ inline void set_pixel_runs(TraceArgs & a, uint32_t run_pixels)
   a.s_row_mod = 0u;
 }
 
+// Kernels whose waves note their queue reservations in a log of `log_entries` words each and add up their own pixels
+// when they run out of work (rt_hip.hip kLogEntries): the reservation sizes for a queue of `queue_items` positions
+// worked off by `waves` waves.  A wave makes its share of the reservations and a few dozen shrinking ones at the
+// end of the queue; four times the average has to fit its log, so queues of many windows get longer reservations
+// (`exact`: tests with small logs skip this, they want full logs).  And however the waves divide the queue, the
+// logs together hold every reservation it can be cut into: a wave whose log is full takes no more, every
+// reservation but the last takes batch_min positions or more, and a wave's last entry may lie past the end of the
+// queue -- so waves * (log_entries - 1) * batch_min must cover the queue.  window: positions per queue window (64);
+// max_windows: the most a log word can record.  ok = false: no such sizes (the frame keeps the separate passes).
+struct LogPlan
+{
+  bool ok;
+  uint32_t batch_items, batch_min;
+};
+inline LogPlan plan_wave_logs(uint32_t queue_items, uint32_t waves, uint32_t batch_items, uint32_t batch_min,
+                              uint32_t log_entries, bool exact, uint32_t window, uint32_t max_windows)
+{
+  LogPlan plan = {false, batch_items, batch_min};
+  if (queue_items == 0u || waves == 0u || log_entries < 2u || window == 0u)
+    return plan;
+  unsigned long long const windows = ((unsigned long long)queue_items + window - 1u) / window;
+  unsigned long long batch_windows = std::max<unsigned long long>(batch_items / window, 1u);
+  if (!exact)
+  {
+    if (log_entries <= 64u)
+      return plan;
+    unsigned long long const room = (unsigned long long)waves * (log_entries - 64u);
+    batch_windows = std::max(batch_windows, (4u * windows + room - 1u) / room);
+  }
+  unsigned long long const hold = (unsigned long long)waves * (log_entries - 1u);
+  unsigned long long const min_windows =
+      std::max<unsigned long long>(std::max<unsigned long long>(batch_min / window, 1u), (windows + hold - 1u) / hold);
+  batch_windows = std::max(batch_windows, min_windows);
+  if (batch_windows > max_windows)
+    return plan;
+  plan.ok = true;
+  plan.batch_items = (uint32_t)batch_windows * window;
+  plan.batch_min = (uint32_t)min_windows * window;
+  return plan;
+}
+
 // Bound on |D_s - D_c| between the direction through the middle of a sub-sample column and the direction of
 // any of its samples: the unnormalised directions differ by at most |up| * cell_y / 2 and are at least
 // znear * |dir| long; the slack covers the approximate normalisation of D_c and float rounding.
