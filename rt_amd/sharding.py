@@ -65,30 +65,48 @@ class RunGather:
         counts = [int((owner == r).sum().item()) for r in range(self.world)]
         self.count = max(counts) if counts else 0  # every rank sends this many pixels (the rest of a short share: padding)
         self.own = pixel[owner == rank]
-        # on the root: where every other rank's pixels go
-        self.theirs = [pixel[owner == r] if (rank == root and r != root) else None for r in range(self.world)]
         self.bytes_per_rank = 3 * 4 * self.count
+        # On the root, one pair of index vectors for all the other ranks' pixels: element (r, plane, j) of what was
+        # received, flat, goes to element (plane, pixel) of the planes, flat -- the whole unpacking is one indexed
+        # read and one indexed write, whatever the number of ranks.
+        self.src = self.dst = None
+        if rank == root and self.world > 1:
+            src, dst = [], []
+            for r in range(self.world):
+                if r == root:
+                    continue
+                theirs = pixel[owner == r]
+                j = torch.arange(theirs.numel(), device=device)
+                for plane in range(3):
+                    src.append((r * 3 + plane) * self.count + j)
+                    dst.append(plane * n_pixels + theirs)
+            self.src, self.dst = torch.cat(src), torch.cat(dst)
 
     def pack(self, planes):
-        """This rank's own pixels, 3 x count (a short share padded with zeros)."""
-        packed = planes.new_zeros((3, self.count))
-        packed[:, : self.own.numel()] = planes.view(3, self.n)[:, self.own]
+        """This rank's own pixels, 3 x count (the rest of a short share is padding that nobody reads)."""
+        view = planes.view(3, self.n)
+        if self.own.numel() == self.count:
+            packed = planes.new_empty((3, self.count))
+            torch.index_select(view, 1, self.own, out=packed)
+        else:
+            packed = planes.new_zeros((3, self.count))
+            packed[:, : self.own.numel()] = view[:, self.own]
         return packed
 
     def unpack(self, planes, received):
-        """On the root: received[r] (what rank r packed) goes where rank r's pixels belong."""
-        view = planes.view(3, self.n)
-        for r, where in enumerate(self.theirs):
-            if where is not None and where.numel():
-                view[:, where] = received[r][:, : where.numel()]
+        """On the root: received[r] (what rank r packed; world x 3 x count, contiguous) goes where rank r's pixels
+        belong."""
+        if self.dst is not None and self.dst.numel():
+            planes.view(-1).index_copy_(0, self.dst, received.view(-1).index_select(0, self.src))
         return planes
 
     def start(self, dist, planes):
         if self.world == 1:
             return None
         packed = self.pack(planes)
-        received = [torch.empty_like(packed) for _ in range(self.world)] if self.rank == self.root else None
-        work = dist.gather(packed, received, dst=self.root, async_op=True)
+        received = planes.new_empty((self.world, 3, self.count)) if self.rank == self.root else None
+        work = dist.gather(packed, [received[r] for r in range(self.world)] if received is not None else None,
+                           dst=self.root, async_op=True)
         return work, packed, received
 
     def finish(self, handle, planes):

@@ -124,5 +124,5 @@ def test_gather_of_each_slices_runs_rebuilds_the_frame(hip, ffi, scenes):
         packed.append(g.pack(planes))
         assert g.bytes_per_rank <= 12 * (n // world + 64)
     root = sharding.RunGather(n, world, 0, "cuda")
-    root.unpack(slices[0], packed)
+    root.unpack(slices[0], torch.stack(packed))  # what the gather delivers: world x 3 x count
     assert torch.equal(slices[0], whole)
