@@ -3,7 +3,9 @@ fold and accumulate passes (RT_HIP_NO_WAVE_SUMS=1): the planes of rt_hip_trace_d
 counters included, on whole frames, slices by samples and by runs of pixels; then the two are timed (trace kernel
 alone, the whole call, and a stream of frames on two streams).
 
-python tools/wave_sums_check.py [quick | time]
+python tools/wave_sums_check.py [quick | time | fuzz SECONDS [SEED]]
+fuzz: random frames large enough to fill the chip (so that the waves take the sums without being told to), random
+sample counts, slices by samples and by runs, both demo scenes and a 100-sphere scene, until the time is up.
 """
 import os
 import sys
@@ -54,7 +56,7 @@ cases = [
 ]
 if quick:
     cases = cases[:8]
-if timing_only:
+if timing_only or (len(sys.argv) > 1 and sys.argv[1] == "fuzz"):
     cases = []
 bad = 0
 for name, demo, spheres, fr, sl in cases:
@@ -71,6 +73,38 @@ for name, demo, spheres, fr, sl in cases:
         d = (a != b).nonzero().flatten()
         print("   %d of %d values differ, first at %s: %s against %s" % (d.numel(), a.numel(), d[:6].tolist(), a[d[:6]].tolist(), b[d[:6]].tolist()))
     bad += (not same) + (not counters)
+
+if len(sys.argv) > 2 and sys.argv[1] == "fuzz":
+    import numpy as np
+
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    scenes = [ffi.Scene.demo(1, 1), ffi.Scene.demo(2, 1), ffi.Scene.demo(3, 1, 100)]
+    t_end = time.time() + float(sys.argv[2])
+    n = taken = 0
+    while time.time() < t_end:
+        scene = scenes[int(rng.integers(len(scenes)))]
+        s = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+        w, h = int(rng.integers(300, 2200)), int(rng.integers(200, 1300))
+        if w * h * s * s > 600e6:
+            continue
+        world = int(rng.choice([1, 1, 2, 3, 8]))
+        rank = int(rng.integers(world))
+        by_runs = bool(rng.integers(2))
+        mk = lambda: ffi.params(w, h, s, seed=int(rng.integers(1, 1000)))  # noqa: E731
+        p = sharding.slice_params(mk, rank, world, pixel_runs=by_runs) if world > 1 else mk()
+        passes(False)
+        took = r.describe(scene, p).wave_sums
+        a, sa = planes_of(scene, p, False)
+        b, sb = planes_of(scene, p, True)
+        n += 1
+        taken += took
+        if not torch.equal(a, b) or sa[:4] != sb[:4]:
+            print("DIFFER: %dx%d s=%d slice %d/%d %s" % (w, h, s, rank, world, "runs" if by_runs else "samples"))
+            bad += 1
+    print("%d frames, %d of them summed by the waves" % (n, taken))
+    r.close()
+    print("FAILED: %d" % bad if bad else "all identical")
+    sys.exit(1 if bad else 0)
 
 if not quick:
     streams = [torch.cuda.Stream(priority=-(i % 2)) for i in range(2)]
