@@ -2003,7 +2003,8 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   }
   rt_hip_scene::Occupancy const shape = launch_shape(scene, p->flags, library_math);
   bool const full_grid = blocks >= shape.per_cu * std::max(g_lib.compute_units, 1) - kSnapshotReserveBlocks;
-  if (!t.fused && t.work != nullptr && a.s_row <= kItemBatch && (kItemBatch % a.s_row) == 0u && a.queue_items != 0u &&
+  bool const have_work = t.work != nullptr || t.describe != nullptr;  // (a description assumes a workspace of work_bytes)
+  if (!t.fused && have_work && a.s_row <= kItemBatch && (kItemBatch % a.s_row) == 0u && a.queue_items != 0u &&
       shape.log_fits && (full_grid || forced) && std::getenv("RT_HIP_NO_WAVE_SUMS") == nullptr)
   {
     LogPlan const plan = plan_wave_logs(a.queue_items, a.guide_waves, a.batch_items, a.batch_min, log_entries, forced,
@@ -2020,14 +2021,17 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   // Sample sharing at the end of the queue, when the caller brought room for this grid's records and colours.
   size_t const lanes = (size_t)blocks * kBlock;
   size_t const share_at = share_offset(p, t.fused);
-  if (t.work != nullptr && t.work_bytes >= share_at + share_bytes_for(lanes, share_depth(p)) && !share_disabled())
+  if (have_work && t.work_bytes >= share_at + share_bytes_for(lanes, share_depth(p)) && !share_disabled())
   {
-    unsigned char * const base = reinterpret_cast<unsigned char *>(t.work) + share_at;
-    a.split_count = reinterpret_cast<uint32_t *>(base);
-    a.splits = reinterpret_cast<u4 *>(base + 16);
-    a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
-    a.shared_off = (size_t)(a.shared - t.work);
     a.share_depth = share_depth(p);
+    if (t.work != nullptr)
+    {
+      unsigned char * const base = reinterpret_cast<unsigned char *>(t.work) + share_at;
+      a.split_count = reinterpret_cast<uint32_t *>(base);
+      a.splits = reinterpret_cast<u4 *>(base + 16);
+      a.shared = reinterpret_cast<float *>(base + 16 + lanes * sizeof(u4));
+      a.shared_off = (size_t)(a.shared - t.work);
+    }
   }
   if (t.describe != nullptr)
   {
@@ -2829,9 +2833,7 @@ int rt_hip_describe_launch(const rt_hip_scene * scene, const rt_hip_camera * cam
     return fail(RT_HIP_ERR_INVALID, "null argument");
   bool const fused = frame_ring_slots(scene, params, needs_library_math(scene, camera)) != 0u;
   TraceTarget t;
-  // (nothing is read or written through these: a workspace of the size rt_hip_trace_device would bring)
-  t.work = reinterpret_cast<float *>(static_cast<uintptr_t>(256));
-  t.work_bytes = trace_buffer_bytes(params, fused);
+  t.work_bytes = trace_buffer_bytes(params, fused);  // the workspace rt_hip_trace_device would bring
   t.describe = out;
   return launch_trace(scene, camera, params, t, nullptr);
 }
