@@ -164,7 +164,7 @@ def test_sample_sharing_changes_no_bit(hip, ffi, scenes, monkeypatch, width, hei
         np.testing.assert_array_equal(shared, plain)
         assert (ss.samples, ss.ray_queries, ss.hit_queries, ss.shaded_bounces) == \
                (sp.samples, sp.ray_queries, sp.hit_queries, sp.shaded_bounces)
-        # RT_HIP_FLAG_PIPELINED is a hint (it once changed how work is reserved): the image must not change
+        # RT_HIP_FLAG_PIPELINED is a hint (it changes how work is reserved at the end of the queue): the image must not change
         q = ffi.params(width, height, s, seed=6, slice_index=slices - 1, slice_count=slices, flags=ffi.FLAG_PIPELINED)
         piped, _ = hip.render(scene, q)
         np.testing.assert_array_equal(piped, plain)
