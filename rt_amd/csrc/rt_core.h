@@ -384,6 +384,7 @@ struct TraceArgs
   uint32_t queue_items;       // positions in this launch's queue (n_items without runs)
   uint32_t run_items, run_stride, run_first;
   uint32_t log_entries;       // kernels whose waves note their reservations (rt_hip.hip kLogEntries): how many a wave may note
+  uint32_t log_quantum;       // ... and the number of queue positions every reservation of theirs is a multiple of
   uint32_t batch_items;       // queue positions a wave reserves at a time ...
   uint32_t batch_min;         // ... and near the end of the queue (see rt_hip.hip ItemPool)
   uint32_t guide_waves;       // waves of the launch

@@ -43,6 +43,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -394,6 +395,7 @@ struct PixelRing
 constexpr uint32_t kLogEntries = 384;
 constexpr uint32_t kLogWords = kLogEntries + 2u * 64u;
 constexpr uint32_t kLogMaxWindows = 64;   // windows of a reservation (6 bits of the word)
+constexpr uint32_t kLogMaxQuantum = 8;    // windows of the smallest reservation that holds whole pixels (EndArgs::quantum)
 struct EndArgs
 {
   float * partial;
@@ -401,13 +403,21 @@ struct EndArgs
   const float * shared;
   uint32_t n_pixels, n_items, queue_items, run_items, run_stride, run_first, s_row, slice_count, share_depth;
   uint32_t log_entries;  // reservations a wave may note (<= kLogEntries; fewer in tests of what happens when a log is full)
+  uint32_t quantum;      // every reservation is a multiple of this many queue positions and starts at one: the least
+                         // common multiple of the 64-position window and s_row, so that it holds whole pixels
+  uint32_t pad[3];
 };
-static_assert(sizeof(EndArgs) == 64, "EndArgs is read back word by word");
+static_assert(sizeof(EndArgs) == 80, "EndArgs is read back word by word");
 constexpr size_t kLogBlockBytes = sizeof(EndArgs) + sizeof(uint32_t) * kLogWords * (kBlock / 64);
 __device__ __forceinline__ uint32_t log_entries()
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   return reinterpret_cast<const EndArgs *>(lds_raw)->log_entries;
+}
+__device__ __forceinline__ uint32_t log_quantum()
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const EndArgs *>(lds_raw)->quantum);
 }
 __device__ __forceinline__ uint32_t * wave_log()
 {
@@ -445,7 +455,11 @@ struct ItemPool
       {
         unsigned long long const seen = (unsigned long long)reserved_end + (unsigned long long)A.guide_waves * last_size;
         unsigned long long const left = seen < A.queue_items ? A.queue_items - seen : 0ull;
-        unsigned long long const want = left / ((unsigned long long)kGuide * A.guide_waves) / kItemBatch * kItemBatch;
+        // (whole windows; kernels with a log: whole pixels too, see EndArgs::quantum)
+        unsigned long long quantum = kItemBatch;
+        if constexpr (kLog)
+          quantum = log_quantum();
+        unsigned long long const want = left / ((unsigned long long)kGuide * A.guide_waves) / quantum * quantum;
         size = (uint32_t)min(max(want, (unsigned long long)A.batch_min), (unsigned long long)A.batch_items);
       }
       last_size = size;
@@ -967,6 +981,8 @@ __device__ __forceinline__ void park_end_args(const TraceArgs & A)
   e->slice_count = A.slice_count;
   e->share_depth = A.share_depth;
   e->log_entries = min(A.log_entries, kLogEntries);
+  e->quantum = A.log_quantum;
+  e->pad[0] = e->pad[1] = e->pad[2] = 0u;
 }
 __device__ __forceinline__ EndArgs read_end_args()
 {
@@ -990,14 +1006,18 @@ __device__ __forceinline__ uint32_t end_queue_item(const EndArgs & E, uint32_t p
 }
 
 // The end of a wave in the kernels with kLog (see kLogEntries): fold pass and accumulate pass over the wave's own
-// columns.  log: the wave's log; entries: reservations it made; stage: LDS of the wave, room for kStageWindows
-// windows of column sums.  s_row divides the 64-item window, so a window holds whole pixels and starts at one.
-// The windows are read kGroupWindows at a time (three loads per lane and window, all in flight together: the wave
-// pays the memory's latency once per group, and it has the registers now), then summed kStageWindows at a time.
-constexpr uint32_t kStageWindows = 2;
-constexpr uint32_t kGroupWindows = 8;
-constexpr uint32_t kListWindows = 96;   // window positions the wave lists at a time (in the 128 words of the split table)
-static_assert(kListWindows % kGroupWindows == 0u && kGroupWindows % kStageWindows == 0u && kListWindows + 3u <= 128u, "");
+// columns.  log: the wave's log; entries: reservations it made; stage: LDS of the wave, room for one chunk of column
+// sums.  Every reservation is a whole number of `quantum` positions (EndArgs::quantum) and starts at one; a quantum
+// holds whole pixels and lies in one run of pixels, so its columns are consecutive items.  It is worked off in chunks
+// of whole pixels, at most kChunkColumns columns each: the wave lists its chunks (position, columns) kListChunks at
+// a time, reads kGroupChunks chunks per round (up to six loads per lane and chunk, 64 consecutive floats per load
+// instruction, all in flight together: the wave pays the memory's latency once per group, and it has the registers
+// now), parks one chunk at a time in LDS and lets lane (pixel, plane) add the pixel's columns.
+constexpr uint32_t kChunkColumns = 128;  // 1536 B of column sums: fits the wave's prepared-column table
+constexpr uint32_t kChunkLoads = 3u * kChunkColumns / 64u;
+constexpr uint32_t kGroupChunks = 4;
+constexpr uint32_t kListChunks = 48;     // two words each, in the 128 words of the split table
+static_assert(kListChunks % kGroupChunks == 0u && 2u * kListChunks + 3u <= 128u, "");
 __device__ __forceinline__ float load_written(const float * p)
 {
   // written earlier by this wave: read past the vector cache, which may hold an older copy of the line
@@ -1009,75 +1029,73 @@ __device__ __forceinline__ void wave_fence()
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ uint32_t listed(const uint32_t * list, uint32_t k, uint32_t n)
-{
-  return k < n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)list[k]) : RT_INVALID;
-}
-// Pixel sums of the windows in `stage` (list[first .. first + kStageWindows), as far as the list goes): the accumulate
-// pass of each pixel and plane, 0 + column 0 + column 1 + ... as colsum_kernel adds them.
+// Pixel sums of the chunk in `stage` (`columns` column sums from queue position `pos` on): the accumulate pass of
+// each pixel and plane, 0 + column 0 + column 1 + ... as colsum_kernel adds them.  kS: s_row (0: any).
 template <uint32_t kS>
-__device__ __forceinline__ void sum_stage(const EndArgs & E, const float * stage, const uint32_t * list, uint32_t first, uint32_t n,
-                                          uint32_t lane)
+__device__ __forceinline__ void sum_chunk(const EndArgs & E, const float * stage, uint32_t pos, uint32_t columns, uint32_t lane)
 {
-  constexpr uint32_t kChains = 3u * (kItemBatch / kS);  // sums of a window: a pixel's red, green, blue
-  for (uint32_t c = lane; c < kStageWindows * kChains; c += 64u)
+  uint32_t const s_row = kS != 0u ? kS : E.s_row;
+  uint32_t const chains = 3u * (columns / s_row);  // sums of the chunk: a pixel's red, green, blue
+  size_t const first_pixel = (size_t)(end_queue_item(E, pos) / s_row);
+  for (uint32_t c = lane; c < chains; c += 64u)
   {
-    uint32_t const k = c / kChains, r = c - k * kChains;
-    uint32_t const pixel = r / 3u, plane = r - 3u * pixel;
-    if (first + k < n)
+    uint32_t const pixel = c / 3u, plane = c - 3u * pixel;
+    const float * v = stage + 3u * pixel * s_row + plane;
+    float sum = 0.0f;
+    if constexpr (kS != 0u)
     {
-      uint32_t const at = list[first + k];
-      if (at < E.queue_items && pixel * kS < E.queue_items - at)
-      {
-        const float * v = stage + k * 3u * kItemBatch + 3u * pixel * kS + plane;
-        float sum = 0.0f;
 #pragma unroll 16
-        for (uint32_t i = 0; i < kS; ++i)
-          sum += v[3u * i];
-        size_t const px = (size_t)(end_queue_item(E, at) / kS) + pixel;
-        if (px < E.n_pixels)
-          E.planes[(size_t)plane * E.n_pixels + px] = sum;
-      }
+      for (uint32_t i = 0; i < kS; ++i)
+        sum += v[3u * i];
     }
+    else
+      for (uint32_t i = 0; i < s_row; ++i)
+        sum += v[3u * i];
+    size_t const px = first_pixel + pixel;
+    if (px < E.n_pixels)
+      E.planes[(size_t)plane * E.n_pixels + px] = sum;
   }
 }
-// The listed windows, kGroupWindows at a time: three loads per lane and window, all in flight together (64
-// consecutive floats per load instruction), then summed kStageWindows at a time.
+// The listed chunks (list[2 k] = position, list[2 k + 1] = columns), kGroupChunks at a time.
 template <uint32_t kS>
-__device__ __forceinline__ void sum_windows(const EndArgs & E, const uint32_t * list, uint32_t n, float * stage, uint32_t lane)
+__device__ __forceinline__ void sum_chunks(const EndArgs & E, const uint32_t * list, uint32_t n, float * stage, uint32_t lane)
 {
-  for (uint32_t g = 0; g < n; g += kGroupWindows)
+  for (uint32_t g = 0; g < n; g += kGroupChunks)
   {
-    float v[kGroupWindows][3];
+    float v[kGroupChunks][kChunkLoads];
 #pragma unroll
-    for (uint32_t k = 0; k < kGroupWindows; ++k)
+    for (uint32_t k = 0; k < kGroupChunks; ++k)
     {
-      uint32_t const pos = listed(list, g + k, n);
 #pragma unroll
-      for (uint32_t j = 0; j < 3u; ++j)
+      for (uint32_t j = 0; j < kChunkLoads; ++j)
         v[k][j] = 0.0f;
-      if (pos < E.queue_items)
+      if (g + k < n)
       {
-        uint32_t const floats = 3u * min(kItemBatch, E.queue_items - pos);
-        const float * const src = E.partial + 3u * (size_t)end_queue_item(E, pos);
+        uint32_t const pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * (g + k)]);
+        uint32_t const columns = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * (g + k) + 1u]);
+        if (pos < E.queue_items && columns <= kChunkColumns && columns <= E.queue_items - pos)
+        {
+          const float * const src = E.partial + 3u * (size_t)end_queue_item(E, pos);
 #pragma unroll
-        for (uint32_t j = 0; j < 3u; ++j)
-          if (lane + 64u * j < floats)
-            v[k][j] = load_written(src + lane + 64u * j);
+          for (uint32_t j = 0; j < kChunkLoads; ++j)
+            if (lane + 64u * j < 3u * columns)
+              v[k][j] = load_written(src + lane + 64u * j);
+        }
       }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < kGroupWindows; k += kStageWindows)
+    for (uint32_t k = 0; k < kGroupChunks; ++k)
     {
       if (g + k < n)
       {
+        uint32_t const pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * (g + k)]);
+        uint32_t const columns = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * (g + k) + 1u]);
 #pragma unroll
-        for (uint32_t q = 0; q < kStageWindows; ++q)
-#pragma unroll
-          for (uint32_t j = 0; j < 3u; ++j)
-            stage[q * 3u * kItemBatch + lane + 64u * j] = v[k + q][j];
+        for (uint32_t j = 0; j < kChunkLoads; ++j)
+          stage[lane + 64u * j] = v[k][j];
         wave_fence();
-        sum_stage<kS>(E, stage, list, g + k, n, lane);
+        if (pos < E.queue_items && columns <= kChunkColumns && columns <= E.queue_items - pos)
+          sum_chunk<kS>(E, stage, pos, columns, lane);
         wave_fence();
       }
     }
@@ -1108,44 +1126,60 @@ __device__ __forceinline__ void wave_sums(uint32_t * log, uint32_t entries, floa
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   wave_fence();
   uint32_t * const list = log + kLogEntries;  // the split table has done its work
-  uint32_t e = 0, w = 0;                      // the next window to list: entry, window of it
+  // whole pixels per chunk; a quantum is a whole number of pixels too, so chunks never reach across one
+  uint32_t const chunk = kChunkColumns / E.s_row * E.s_row;
+  uint32_t const quantum = E.quantum != 0u ? E.quantum : kItemBatch;
+  uint32_t e = 0, off = 0;                    // the next columns to list: entry, position in its reservation
   for (;;)
   {
     if (lane == 0u)
     {
       uint32_t n = 0;
-      while (e < entries && n < kListWindows)
+      while (e < entries && n < kListChunks)
       {
         uint32_t const rec = log[e];
-        uint32_t const first_pos = rec & ~(kItemBatch - 1u), windows = (rec & (kItemBatch - 1u)) + 1u;
-        for (; w < windows && n < kListWindows; ++w)
-          if (first_pos + w * kItemBatch < E.queue_items)
-            list[n++] = first_pos + w * kItemBatch;
-        if (w == windows)
+        uint32_t const first_pos = rec & ~(kItemBatch - 1u), length = ((rec & (kItemBatch - 1u)) + 1u) * kItemBatch;
+        while (off < length && n < kListChunks)
+        {
+          uint32_t const pos = first_pos + off;
+          if (pos >= E.queue_items || chunk == 0u)
+          {
+            off = length;
+            break;
+          }
+          uint32_t const columns = min(min(chunk, quantum - off % quantum), E.queue_items - pos);
+          list[2u * n] = pos;
+          list[2u * n + 1u] = columns;
+          n += 1u;
+          off += columns;
+        }
+        if (off >= length)
         {
           e += 1u;
-          w = 0u;
+          off = 0u;
         }
       }
-      list[kListWindows] = n;
-      list[kListWindows + 1u] = e;
-      list[kListWindows + 2u] = w;
+      list[2u * kListChunks] = n;
+      list[2u * kListChunks + 1u] = e;
+      list[2u * kListChunks + 2u] = off;
     }
     wave_fence();
-    uint32_t const n = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[kListWindows]);
-    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[kListWindows + 1u]);
-    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[kListWindows + 2u]);
+    uint32_t const n = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * kListChunks]);
+    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * kListChunks + 1u]);
+    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2u * kListChunks + 2u]);
     if (n == 0u)
       break;
     switch (E.s_row)
     {
-    case 1: sum_windows<1>(E, list, n, stage, lane); break;
-    case 2: sum_windows<2>(E, list, n, stage, lane); break;
-    case 4: sum_windows<4>(E, list, n, stage, lane); break;
-    case 8: sum_windows<8>(E, list, n, stage, lane); break;
-    case 16: sum_windows<16>(E, list, n, stage, lane); break;
-    case 32: sum_windows<32>(E, list, n, stage, lane); break;
-    default: sum_windows<64>(E, list, n, stage, lane); break;
+    case 1: sum_chunks<1>(E, list, n, stage, lane); break;
+    case 2: sum_chunks<2>(E, list, n, stage, lane); break;
+    case 4: sum_chunks<4>(E, list, n, stage, lane); break;
+    case 8: sum_chunks<8>(E, list, n, stage, lane); break;
+    case 10: sum_chunks<10>(E, list, n, stage, lane); break;
+    case 16: sum_chunks<16>(E, list, n, stage, lane); break;
+    case 32: sum_chunks<32>(E, list, n, stage, lane); break;
+    case 64: sum_chunks<64>(E, list, n, stage, lane); break;
+    default: sum_chunks<0>(E, list, n, stage, lane); break;
     }
     wave_fence();
   }
@@ -2004,16 +2038,26 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   rt_hip_scene::Occupancy const shape = launch_shape(scene, p->flags, library_math);
   bool const full_grid = blocks >= shape.per_cu * std::max(g_lib.compute_units, 1) - kSnapshotReserveBlocks;
   bool const have_work = t.work != nullptr || t.describe != nullptr;  // (a description assumes a workspace of work_bytes)
-  if (!t.fused && have_work && a.s_row <= kItemBatch && (kItemBatch % a.s_row) == 0u && a.queue_items != 0u &&
+  // A reservation has to hold whole pixels: its size is a multiple of the least common multiple of the window and
+  // s_row (one window for 1, 2, 4 ... 64 samples per row, five for 10 or 20, three for 12), which must stay small,
+  // and a chunk of kChunkColumns columns has to hold at least one pixel.
+  // Where that makes the smallest reservation larger than it would be, only frames in a stream take the path: the
+  // end of a frame traced on its own gets longer by more than the passes cost (1024x768 10x10, reservations of five
+  // windows instead of two at the end: 3.47 ms against 3.09 alone, 2.80 against 2.96 in a stream).
+  uint32_t const quantum_windows = a.s_row / std::gcd(a.s_row, kItemBatch);
+  bool const coarser = quantum_windows * kItemBatch > a.batch_min;
+  if (!t.fused && have_work && a.s_row <= kChunkColumns && quantum_windows <= kLogMaxQuantum && a.queue_items != 0u &&
+      (!coarser || (p->flags & RT_HIP_FLAG_PIPELINED) != 0u || forced) &&
       shape.log_fits && (full_grid || forced) && std::getenv("RT_HIP_NO_WAVE_SUMS") == nullptr)
   {
     LogPlan const plan = plan_wave_logs(a.queue_items, a.guide_waves, a.batch_items, a.batch_min, log_entries, forced,
-                                        kItemBatch, kLogMaxWindows);
+                                        kItemBatch, kLogMaxWindows, quantum_windows);
     if (plan.ok)
     {
       a.batch_items = plan.batch_items;
       a.batch_min = plan.batch_min;
       a.log_entries = log_entries;
+      a.log_quantum = quantum_windows * kItemBatch;
       t.wave_sums = true;
     }
   }

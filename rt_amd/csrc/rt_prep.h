@@ -70,17 +70,19 @@ inline void set_pixel_runs(TraceArgs & a, uint32_t run_pixels)
 // logs together hold every reservation it can be cut into: a wave whose log is full takes no more, every
 // reservation but the last takes batch_min positions or more, and a wave's last entry may lie past the end of the
 // queue -- so waves * (log_entries - 1) * batch_min must cover the queue.  window: positions per queue window (64);
-// max_windows: the most a log word can record.  ok = false: no such sizes (the frame keeps the separate passes).
+// max_windows: the most a log word can record; quantum_windows: every reservation is a multiple of this many windows
+// (so that it holds whole pixels).  ok = false: no such sizes (the frame keeps the separate passes).
 struct LogPlan
 {
   bool ok;
   uint32_t batch_items, batch_min;
 };
 inline LogPlan plan_wave_logs(uint32_t queue_items, uint32_t waves, uint32_t batch_items, uint32_t batch_min,
-                              uint32_t log_entries, bool exact, uint32_t window, uint32_t max_windows)
+                              uint32_t log_entries, bool exact, uint32_t window, uint32_t max_windows,
+                              uint32_t quantum_windows = 1u)
 {
   LogPlan plan = {false, batch_items, batch_min};
-  if (queue_items == 0u || waves == 0u || log_entries < 2u || window == 0u)
+  if (queue_items == 0u || waves == 0u || log_entries < 2u || window == 0u || quantum_windows == 0u)
     return plan;
   unsigned long long const windows = ((unsigned long long)queue_items + window - 1u) / window;
   unsigned long long batch_windows = std::max<unsigned long long>(batch_items / window, 1u);
@@ -92,9 +94,11 @@ inline LogPlan plan_wave_logs(uint32_t queue_items, uint32_t waves, uint32_t bat
     batch_windows = std::max(batch_windows, (4u * windows + room - 1u) / room);
   }
   unsigned long long const hold = (unsigned long long)waves * (log_entries - 1u);
-  unsigned long long const min_windows =
+  unsigned long long min_windows =
       std::max<unsigned long long>(std::max<unsigned long long>(batch_min / window, 1u), (windows + hold - 1u) / hold);
+  min_windows = (min_windows + quantum_windows - 1u) / quantum_windows * quantum_windows;
   batch_windows = std::max(batch_windows, min_windows);
+  batch_windows = (batch_windows + quantum_windows - 1u) / quantum_windows * quantum_windows;
   if (batch_windows > max_windows)
     return plan;
   plan.ok = true;

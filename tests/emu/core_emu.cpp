@@ -147,9 +147,10 @@ extern "C" uint32_t emu_pixel_run_queue(uint32_t n_pixels, uint32_t s_row, uint3
 
 // rt_prep.h plan_wave_logs: out = {ok, batch_items, batch_min}.
 extern "C" void emu_plan_wave_logs(uint32_t queue_items, uint32_t waves, uint32_t batch_items, uint32_t batch_min,
-                                   uint32_t log_entries, int exact, uint32_t * out3)
+                                   uint32_t log_entries, int exact, uint32_t quantum_windows, uint32_t * out3)
 {
-  rtc::LogPlan const plan = rtc::plan_wave_logs(queue_items, waves, batch_items, batch_min, log_entries, exact != 0, 64u, 64u);
+  rtc::LogPlan const plan = rtc::plan_wave_logs(queue_items, waves, batch_items, batch_min, log_entries, exact != 0, 64u, 64u,
+                                                quantum_windows);
   out3[0] = plan.ok ? 1u : 0u;
   out3[1] = plan.batch_items;
   out3[2] = plan.batch_min;

@@ -1,6 +1,6 @@
 """Pixel sums taken by the waves of the resident trace kernels as they run out of work (the default for launches that
-fill the chip and whose 64-column queue windows hold whole pixels) against the fold and accumulate passes
-(RT_HIP_NO_WAVE_SUMS): the wave that wrote a window's column sums adds them in the order the passes would, so planes,
+fill the chip, where a few 64-column queue windows hold whole pixels) against the fold and accumulate passes
+(RT_HIP_NO_WAVE_SUMS): the wave that wrote a pixel's column sums adds them in the order the passes would, so planes,
 images and counters must be identical bit for bit.  Small test frames do not fill the chip; RT_HIP_LOG_ENTRIES makes
 them take the path anyway, and with a small number it also fills the waves' reservation logs, after which a wave
 takes no more work and leaves the rest of the queue to the others.
@@ -45,7 +45,14 @@ CASES = [
     (1, 0, 333, 200, 16, (2, 8, True), "384"),       # slice by runs of 64 pixels: the other runs' sums are zero
     (1, 0, 31, 17, 32, (5, 7, True), "384"),         # more slices than some of them have runs
     (3, 100, 320, 240, 4, None, "384"),              # 101 spheres: resident, primary rays filtered per sample
-    (1, 0, 640, 360, 16, None, "3"),                 # three reservations per wave: the logs fill up
+    (2, 0, 120, 90, 10, None, "384"),                # the viewer's high-quality mode: a window holds 6.4 pixels, five windows 32
+    (1, 0, 333, 77, 12, (1, 2, True), "384"),        # three windows hold 16 pixels; slices by runs of 64 pixels
+    (1, 0, 150, 100, 3, None, "384"),
+    (2, 0, 97, 53, 5, (2, 3, False), "384"),
+    (2, 0, 100, 60, 20, None, "384"),
+    (1, 0, 40, 30, 128, None, "384"),                # a pixel is two windows
+    (1, 0, 640, 360, 10, None, "3"),                 # three reservations per wave: the logs fill up
+    (1, 0, 640, 360, 16, None, "3"),
     (2, 0, 320, 240, 8, (0, 2, True), "2"),
     (1, 0, 1024, 768, 2, None, "384"),               # the reference's default window
     (2, 0, 1280, 720, 16, None, None),               # as a caller gets it: the launch fills the chip
@@ -148,7 +155,11 @@ def test_which_frames_take_which_path(hip, ffi, scenes):
     stream = hip.describe(pretty, ffi.params(1920, 1080, 16, flags=ffi.FLAG_PIPELINED))
     assert stream.batch_min == 128 and stream.wave_sums == 1
     assert hip.describe(pretty, ffi.params(1024, 768, 2)).wave_sums == 0       # a third of the chip's block slots
-    assert hip.describe(scenes(2), ffi.params(1024, 768, 10)).wave_sums == 0   # 10 does not divide 64
+    # 10x10: reservations of five windows hold 32 whole pixels; worth it in a stream of frames, not for a frame on its own
+    hq = hip.describe(scenes(2), ffi.params(1024, 768, 10, flags=ffi.FLAG_PIPELINED))
+    assert hq.wave_sums == 1 and hq.batch_items % 320 == 0 and hq.batch_min % 320 == 0
+    assert hip.describe(scenes(2), ffi.params(1024, 768, 10)).wave_sums == 0
+    assert hip.describe(pretty, ffi.params(1920, 1080, 9)).wave_sums == 0      # nine windows before a reservation holds whole pixels
     fused = hip.describe(pretty, ffi.params(1920, 1080, 16, flags=ffi.FLAG_KERNEL_SUMS))
     assert (fused.kernel_sums, fused.wave_sums) == (1, 0)
     # 201 spheres with as many materials: resident, but the waves' logs would cost a block per compute unit
