@@ -436,7 +436,7 @@ def main():
         traffic = prof.get("trace_kernel_bytes_per_launch")
         # what the kernel's algorithm moves through HBM: one column sum (12 B) written per sub-sample column; where the
         # kernel's waves add up their own pixels as they end, they read those sums back and write 12 B per pixel
-        plan = renderer.describe(scene, p_alone)
+        plan = renderer.describe(scene, p)  # (the frames of the timed stream)
         column_bytes = 12 * w * h * s * (2 if plan.wave_sums else 1) // (world if by_runs else 1) + (12 * w * h if plan.wave_sums else 0)
         # vector instructions the kernel issued: counted by SQ_INSTS_VALU (64 lanes each) when this workload has a
         # committed counter profile, else modelled from this run's device counters
