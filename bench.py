@@ -376,7 +376,7 @@ def main():
 
         frames = max(3, min(args.steps, 8))
         host_images = [torch.empty(w * h * 3, dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        p_job = ffi.params(w, h, s, seed=1, flags=flags & ~ffi.FLAG_PIPELINED)
+        p_job = ffi.params(w, h, s, seed=1, flags=flags)  # (a stream too: successive jobs take turns on two library streams)
 
         def finish_into(job, k):
             rc = renderer.lib.rt_hip_job_finish(job, host_images[k % 2].data_ptr(), None)
@@ -384,14 +384,21 @@ def main():
                 raise ffi.HipError("rt_hip_job_finish failed (%d): %s" % (rc, renderer.lib.rt_hip_last_error().decode()))
 
         fence()
-        finish_into(renderer.start(scene, p_job), 0)  # buffers of the job path exist from here on
-        finish_into(renderer.start(scene, p_job), 1)
-        t = time.perf_counter()
-        job = renderer.start(scene, p_job)
-        for k in range(frames):
-            nxt = renderer.start(scene, p_job) if k + 1 < frames else None
+        # Three jobs in flight: the one being traced, the one whose first waves take over as that one's last waves
+        # leave (the library gives successive jobs two streams in turn), and one more behind the first, so that what
+        # follows a trace on its stream -- resolve pass, download, the host's next call -- is not what the third waits for.
+        in_flight = 3
+        warm = [renderer.start(scene, p_job) for _ in range(in_flight)]  # buffers of the job path exist from here on
+        for k, job in enumerate(warm):
             finish_into(job, k)
-            job = nxt
+        t = time.perf_counter()
+        jobs = [renderer.start(scene, p_job) for _ in range(min(in_flight - 1, frames))]
+        started = len(jobs)
+        for k in range(frames):
+            if started < frames:
+                jobs.append(renderer.start(scene, p_job))
+                started += 1
+            finish_into(jobs.pop(0), k)
         stream_d2h_ms = (time.perf_counter() - t) / frames * 1e3
         del np
 

@@ -176,9 +176,13 @@ int rt_hip_scene_create(const float * centers_radii, const uint32_t * material_i
                         const rt_hip_light * lights, uint32_t light_count, rt_hip_scene ** out_scene);
 void rt_hip_scene_destroy(rt_hip_scene * scene);
 
-/* Replaces ray_tracing_cuda::RayTrace (rt_cuda/rt_cuda.h:19-23): enqueues one frame on the library's own
- * non-blocking stream and returns immediately with a job handle (instead of a cudaEvent_t).  No host
- * worker thread and no realtimeHandler callback are needed: progress is pulled with rt_hip_job_snapshot. */
+/* Replaces ray_tracing_cuda::RayTrace (rt_cuda/rt_cuda.h:19-23): enqueues one frame on one of the library's own
+ * non-blocking streams and returns immediately with a job handle (instead of a cudaEvent_t).  No host
+ * worker thread and no realtimeHandler callback are needed: progress is pulled with rt_hip_job_snapshot.
+ * Successive jobs take two streams in turn (every job has buffers of its own), so a caller that keeps jobs in
+ * flight -- starts frame k + 2 before it finishes frame k -- gets the end of one trace, the beginning of the next and
+ * the download of the one before side by side (a stream of 1080p 16x16 frames, each downloaded: 17.6 ms per frame
+ * with three in flight, 18.2 with two). */
 int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
                        const rt_hip_trace_params * params, rt_hip_job ** out_job);
 
@@ -189,7 +193,9 @@ int rt_hip_job_poll(rt_hip_job * job);
 /* Replaces ray_tracing_cuda::CopyOutputToBuffer (rt_cuda/rt_cuda.h:29): copies what has been rendered so
  * far (unfinished pixels are black) into rgb without stalling the trace.  The first snapshot of a job allocates its
  * image buffers (two device-synchronising calls, about 2 x 12 bytes per pixel on the device and 12 in pinned host
- * memory); they are released when the job is finished. */
+ * memory); they are released when the job is finished.  A frame too short to be watched while it renders (fewer
+ * than 1.5 G samples, about a tenth of a second) may be traced in a way that leaves nothing to look at before its end:
+ * a snapshot of such a job waits for the frame and returns the finished image. */
 int rt_hip_job_snapshot(rt_hip_job * job, float * rgb);
 
 /* Replaces ray_tracing_cuda::FinishRayTrace (rt_cuda/rt_cuda.h:32): waits for the frame, writes the final

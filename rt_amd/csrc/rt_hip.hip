@@ -1528,7 +1528,11 @@ struct Library
   int clock_khz = 0;
   size_t lds_per_block = 65536;  // what one block may ask for without opting in to more
   char name[256] = {0};
-  hipStream_t stream = nullptr;       // trace launches of the job API
+  hipStream_t stream = nullptr;       // trace launches of the job API ...
+  hipStream_t stream_b = nullptr;     // ... which take turns with this one (a lower priority, so that HIP gives it a
+                                      // hardware queue of its own): the first waves of a job's trace take over the
+                                      // compute units the last waves of the job before it leave
+  unsigned job_turn = 0;              // (under the mutex)
   hipStream_t copy_stream = nullptr;  // snapshots, so they never queue behind a running trace
   // What an rt_hip_trace_device call needs besides its arguments, one set per caller stream so that calls on
   // different streams may overlap: column sums + sample-sharing room, the camera table, counters.  Grow-only.
@@ -1620,6 +1624,7 @@ struct rt_hip_job
   uint32_t * h_cancel = nullptr;  // pinned host word the kernel polls; written by rt_hip_job_cancel
   bool cancelled = false;
   bool fused = false;  // the trace kernel took the pixel sums itself: d_partial holds no column sums
+  bool snapshots_wait = false;  // a short frame whose column sums were not cleared: a snapshot is the finished image
 };
 
 namespace
@@ -1937,6 +1942,7 @@ struct TraceTarget
   bool fused = false;           // out: the kernel took the pixel sums itself
   bool wave_sums = false;       // out: the kernel left column sums and its waves added them up as they ended
   rt_hip_launch_info * describe = nullptr;  // not null: nothing is enqueued, the launch is described here instead
+  bool column_sums_cleared = false;  // out: what a snapshot reads (clear_first) was cleared
 };
 
 // Enqueues, on `stream`: the set-up kernel (camera table for this frame's camera, counters reset), the trace kernel and
@@ -2106,8 +2112,17 @@ int launch_trace(const rt_hip_scene * scene, const rt_hip_camera * camera, const
   };
   if (!t.fused && t.clear_first)
   {
-    zero_floats(t.work, partial_bytes(p) / sizeof(float));
-    RT_CHECK(hipGetLastError());
+    // A frame too short for anyone to look at while it renders (kSnapshotRoomSamples) whose pixel sums the kernel's
+    // waves take keeps its column sums uncleared: 398 MB for a 1080p 16x16 frame, a fill that would sit in front of
+    // the trace on its stream and find block slots only as the previous job's trace leaves them.  A snapshot of such
+    // a job waits for the frame (a tenth of a second at most) and is the finished image.
+    bool const short_job = (unsigned long long)a.queue_items * per_column < kSnapshotRoomSamples;
+    t.column_sums_cleared = !(t.wave_sums && short_job);
+    if (t.column_sums_cleared)
+    {
+      zero_floats(t.work, partial_bytes(p) / sizeof(float));
+      RT_CHECK(hipGetLastError());
+    }
     // (a job may be cancelled: the pixels of windows no wave reserved keep the zero sums the accumulate pass would
     // have given them)
     if (t.wave_sums)
@@ -2306,10 +2321,13 @@ extern "C" {
 static void release_device_state()
 {
   if (g_lib.stream) (void)hipStreamSynchronize(g_lib.stream);
+  if (g_lib.stream_b) (void)hipStreamSynchronize(g_lib.stream_b);
   if (g_lib.copy_stream) (void)hipStreamSynchronize(g_lib.copy_stream);
   if (g_lib.stream) (void)hipStreamDestroy(g_lib.stream);
+  if (g_lib.stream_b) (void)hipStreamDestroy(g_lib.stream_b);
   if (g_lib.copy_stream) (void)hipStreamDestroy(g_lib.copy_stream);
   g_lib.stream = nullptr;
+  g_lib.stream_b = nullptr;
   g_lib.copy_stream = nullptr;
   destroy_job(g_lib.spare_job);
   g_lib.spare_job = nullptr;
@@ -2371,7 +2389,7 @@ int rt_hip_init(int device)
     RT_CHECK(hipSetDevice(g_lib.device));
     release_device_state();
   }
-  if (g_lib.stream || g_lib.copy_stream || g_lib.never_cancel || g_lib.jitter_tab)
+  if (g_lib.stream || g_lib.stream_b || g_lib.copy_stream || g_lib.never_cancel || g_lib.jitter_tab)
   {
     // an earlier rt_hip_init failed half way
     RT_CHECK(hipSetDevice(g_lib.device));
@@ -2389,6 +2407,13 @@ int rt_hip_init(int device)
   g_lib.lds_per_block = std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536u, 65536u);
   std::snprintf(g_lib.name, sizeof(g_lib.name), "%s (%s)", prop.name, prop.gcnArchName);
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
+  {
+    int least = 0, greatest = 0;
+    RT_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // (no priorities on this device: the second stream is an ordinary one, and jobs simply take turns)
+    if (hipStreamCreateWithPriority(&g_lib.stream_b, hipStreamNonBlocking, greatest) != hipSuccess)
+      RT_CHECK(hipStreamCreateWithFlags(&g_lib.stream_b, hipStreamNonBlocking));
+  }
   RT_CHECK(hipStreamCreateWithFlags(&g_lib.copy_stream, hipStreamNonBlocking));
   RT_CHECK(hipMalloc((void **)&g_lib.never_cancel, 64));
   RT_CHECK(hipMemset(g_lib.never_cancel, 0, 64));
@@ -2582,16 +2607,24 @@ int rt_hip_trace_async(const rt_hip_scene * scene, const rt_hip_camera * camera,
   t.ev_stop = job->stop;
   // The pixel sums and the resolve pass follow the trace on its stream, so the image is complete when `done` fires
   // and rt_hip_job_finish only has the download left -- on the copy stream, where it runs beside whatever frame
-  // the trace stream has started next.
-  rc = launch_trace(scene, camera, params, t, g_lib.stream);
+  // the trace streams have started next.  Successive jobs take turns on two streams (every job has buffers of its
+  // own): a caller that starts the next frame before it finishes this one gets the end of one trace and the
+  // beginning of the next side by side.
+  hipStream_t stream = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_lib.mutex);
+    stream = (g_lib.job_turn++ & 1u) != 0u ? g_lib.stream_b : g_lib.stream;
+  }
+  rc = launch_trace(scene, camera, params, t, stream);
   job->fused = t.fused;
+  job->snapshots_wait = !t.fused && !t.column_sums_cleared;
   if (rc == RT_HIP_OK)
-    rc = launch_resolve(job->d_planes, job->d_rgb, params->width, params->height, params->samples_in_row, g_lib.stream);
-  if (rc == RT_HIP_OK && (e = hipEventRecord(job->done, g_lib.stream)) != hipSuccess)
+    rc = launch_resolve(job->d_planes, job->d_rgb, params->width, params->height, params->samples_in_row, stream);
+  if (rc == RT_HIP_OK && (e = hipEventRecord(job->done, stream)) != hipSuccess)
     rc = fail(RT_HIP_ERR_DEVICE, "hipEventRecord", e);
   if (rc != RT_HIP_OK)
   {
-    (void)hipStreamSynchronize(g_lib.stream);
+    (void)hipStreamSynchronize(stream);
     free_job(job);
     return rc;
   }
@@ -2617,6 +2650,15 @@ int rt_hip_job_snapshot(rt_hip_job * job, float * rgb)
     return fail(RT_HIP_ERR_INVALID, "null argument");
   size_t const pixels = (size_t)job->params.width * job->params.height;
   size_t const bytes = 3 * pixels * sizeof(float);
+  if (job->snapshots_wait)
+  {
+    // a frame of well under a tenth of a second, traced without clearing what a snapshot would read: the snapshot
+    // is the finished image
+    RT_CHECK(hipEventSynchronize(job->done));
+    RT_CHECK(hipMemcpyAsync(rgb, job->d_rgb, bytes, hipMemcpyDeviceToHost, g_lib.copy_stream));
+    RT_CHECK(hipStreamSynchronize(g_lib.copy_stream));
+    return RT_HIP_OK;
+  }
   if (job->h_snap == nullptr)
   {
     // (the first snapshot of a job allocates: device-synchronising calls, made while the trace runs)
