@@ -1015,6 +1015,10 @@ RT_FN uint32_t pop_candidate(uint32_t & mask, uint32_t count)
 //                     own pixel sums, TraceArgs::ring_slots)
 //   sphere(i)         exact (cx, cy, cz, r*r) of sphere i;  sphere_material(i);  material(m, k) and
 //                     light(l, k): record k of material m / light l;  jitter_table()
+//   kCompactsRays     the lanes that share loop trips hand their primary rays to the first of them before a round
+//                     over staged tiles: gather_rays(mine, dir, a) turns (has a ray, the ray) into what this lane
+//                     traces and returns the lane the ray came from; return_hits(mine, home, active, t, i) takes
+//                     the results back to the lanes with `active` (both are calls of every lane)
 //   tiles()           number of sphere tiles;  load_tile(k, primary) stages tile k of the filter records
 //                     (the camera table when primary) and returns its padded entry count;  tile_base(k),
 //                     tile_data(primary);  tile_aux(): the per-sphere cone term of the staged filter records
@@ -1211,23 +1215,35 @@ RT_FN void trace_primary(const TraceArgs & A, Env & env, bool active, f3 dir, fl
     RT_REGION(cnt, 3);
     return;
   }
+  // An environment whose waves move in step through the staged tiles (Env::kCompactsRays) first hands the rays of
+  // the lanes that have one to its first lanes: in a round only the lanes without a hit trace a primary ray, about
+  // half of them where paths are long, and a wave none of whose lanes holds a ray skips the arithmetic of the round
+  // (it still takes part in staging the tiles).  Which lane computes a ray changes nothing about its result.
+  bool mine = active;
+  uint32_t home = 0;
+  if constexpr (Env::kCompactsRays)
+    home = env.gather_rays(mine, dir, a);
   for (uint32_t k = 0; k < env.tiles(); ++k)
   {
     uint32_t const tile_count = env.load_tile(k, true);
     uint32_t const tile_base = env.tile_base(k);
     const f4 * tab = env.tile_data(true);
+    if (Env::kCompactsRays && !env.any_wave(mine))
+      continue;
     for (uint32_t c0 = 0; c0 < tile_count; c0 += RT_CHUNK)
     {
       uint32_t const count = (tile_count - c0 < RT_CHUNK) ? (tile_count - c0) : RT_CHUNK;
       RT_REGION(cnt, 1);
       uint32_t mask = filter_chunk_1<Env::kPrimaryUnroll>(tab + c0, count, dir);
-      if (!active)
+      if (!mine)
         mask = 0;
       RT_REGION(cnt, 2);
       resolve_primary(A, env, mask, tile_base + c0, count, dir, a, best_t, best_i, cnt);
       RT_REGION(cnt, 3);
     }
   }
+  if constexpr (Env::kCompactsRays)
+    env.return_hits(mine, home, active, best_t, best_i);
   if (active)
     cnt.filter_tests += 1u;
 }

@@ -634,6 +634,7 @@ template <bool kLibMath, bool kFused, bool kLog = false>
 struct WaveEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
+  static constexpr bool kCompactsRays = false;
   static constexpr uint32_t kFilterUnroll = RT_WAVE_UNROLL;
   static constexpr uint32_t kPrimaryUnroll = 2;  // scenes of 65 to 256 spheres; smaller ones filter per column
   const TraceArgs & A;
@@ -765,10 +766,23 @@ struct WaveEnv
 
 // Larger scenes: the block re-stages the spheres (or the camera table) through one LDS tile inside every
 // pass, so all of its waves take the same trips and every loop decision is block-wide.
-template <bool kLibMath, bool kFused>
+// LDS through which a block's lanes hand their primary rays to its first lanes (BlockEnv::gather_rays): per lane a
+// ray (direction and its squared length), the lane it came from, and the hit that goes back; a count per wave.
+struct RayExchange
+{
+  f4 rays[kBlock];
+  uint32_t homes[kBlock];
+  float hit_t[kBlock];
+  int hit_i[kBlock];
+  uint32_t counts[kBlock / 64];
+};
+static_assert(sizeof(RayExchange) % 16u == 0u, "what follows it in LDS stays 16-byte aligned");
+
+template <bool kLibMath, bool kFused, bool kCompact = false>
 struct BlockEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
+  static constexpr bool kCompactsRays = kCompact;
   static constexpr uint32_t kFilterUnroll = RT_BLOCK_UNROLL;  // almost all of this path's time is the filter
 #ifndef RT_BLOCK_PRIMARY_UNROLL
 #define RT_BLOCK_PRIMARY_UNROLL 4
@@ -781,6 +795,68 @@ struct BlockEnv
   const float * jitter;   // LDS: RT_JITTER_FLOATS
   ItemPool pool;
   PixelRing ring;
+  RayExchange * exchange = nullptr;  // LDS (kCompact)
+
+  // The block's lanes that hold a ray (`mine`) hand it to the block's first lanes, in lane order; afterwards lane j
+  // holds ray j (mine = j < number of rays) and the return value is the lane the ray came from.
+  __device__ __forceinline__ uint32_t gather_rays(bool & mine, f3 & dir, float & a) const
+  {
+    unsigned long long const ballot = __ballot(mine);
+    uint32_t const wave = wave_in_block();
+    if (lane_here() == 0u)
+      exchange->counts[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64u; ++w)
+    {
+      uint32_t const c = exchange->counts[w];
+      before += w < wave ? c : 0u;
+      total += c;
+    }
+    if (mine)
+    {
+      uint32_t const slot = before + lanes_below(ballot);
+      f4 r;
+      r.x = dir.x;
+      r.y = dir.y;
+      r.z = dir.z;
+      r.w = a;
+      exchange->rays[slot] = r;
+      exchange->homes[slot] = threadIdx.x;
+    }
+    __syncthreads();
+    mine = threadIdx.x < total;
+    uint32_t home = 0;
+    if (mine)
+    {
+      f4 const r = exchange->rays[threadIdx.x];
+      dir = mk3(r.x, r.y, r.z);
+      a = r.w;
+      home = exchange->homes[threadIdx.x];
+    }
+    return home;
+  }
+  // ... and the hits go back to the lanes the rays came from (`active`: this lane had handed one in).
+  __device__ __forceinline__ void return_hits(bool mine, uint32_t home, bool active, float & t, int & i) const
+  {
+    if (mine)
+    {
+      exchange->hit_t[home] = t;
+      exchange->hit_i[home] = i;
+    }
+    __syncthreads();
+    if (active)
+    {
+      t = exchange->hit_t[threadIdx.x];
+      i = exchange->hit_i[threadIdx.x];
+    }
+    else
+    {
+      t = 0.0f;
+      i = -1;
+    }
+  }
 
   __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
   __device__ __forceinline__ int count(bool p) const { return __syncthreads_count(p); }
@@ -844,6 +920,7 @@ template <bool kLibMath, bool kFused>
 struct GridEnv
 {
   static constexpr bool kLibraryMath = kLibMath;
+  static constexpr bool kCompactsRays = false;
   static constexpr uint32_t kFilterUnroll = 2;
   static constexpr uint32_t kPrimaryUnroll = 2;
   const TraceArgs & A;
@@ -1212,9 +1289,17 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
   {
     constexpr uint32_t kTile = kForward ? kTileSpheres : kTileSpheresStack;
     float * const cone = reinterpret_cast<float *>(sph + kTile);
-    BlockEnv<kLibMath, kFused> env{A, sph, cone, kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool(), PixelRing()};
+    // (the kernels without path stacks have the LDS for it: the lanes' primary rays are handed to the block's first lanes)
+    constexpr bool kCompact = kForward;
+    BlockEnv<kLibMath, kFused, kCompact> env{A, sph, cone, kOneLight ? A.aux_cone : A.aux_rw, jitter, ItemPool(), PixelRing()};
+    unsigned char * after = reinterpret_cast<unsigned char *>(cone + kTile);
+    if constexpr (kCompact)
+    {
+      env.exchange = reinterpret_cast<RayExchange *>(after);
+      after += sizeof(RayExchange);
+    }
     if constexpr (kFused)
-      env.ring.init(A, reinterpret_cast<unsigned char *>(cone + kTile) + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
+      env.ring.init(A, after + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
     __syncthreads();
     trace_loop<kForward, false, kOneLight>(A, env, stack + threadIdx.x, (uint32_t)kBlock, cnt);
     if constexpr (kFused)
@@ -1687,7 +1772,8 @@ size_t lds_bytes(const rt_hip_scene * sc, uint32_t flags, uint32_t ring_slots)
   if (uses_grid(sc, flags))
     ;
   else if (is_tiled(sc))
-    bytes += (sizeof(f4) + sizeof(float)) * (size_t)(sc->forward_ok ? kTileSpheres : kTileSpheresStack);
+    bytes += (sizeof(f4) + sizeof(float)) * (size_t)(sc->forward_ok ? kTileSpheres : kTileSpheresStack) +
+             (sc->forward_ok ? sizeof(RayExchange) : 0u);
   else
     bytes = resident_lds_bytes(sc);
   bytes += (size_t)(kBlock / 64) * ring_bytes_per_wave(ring_slots);

@@ -13,6 +13,7 @@ struct HostEnv
   static constexpr uint32_t kFilterUnroll = 4;
   static constexpr uint32_t kPrimaryUnroll = 4;
   static constexpr bool kLibraryMath = true;  // (the host build has no other)
+  static constexpr bool kCompactsRays = false;
   const rtc::TraceArgs & A;
   uint32_t total;
   uint32_t tile_size;
