@@ -251,6 +251,14 @@ int rt_hip_resolve_device(const float * d_sum_planes, float * d_rgb, uint32_t wi
  * four comparisons (all zero on a device the library supports).  About 0.1 s. */
 int rt_hip_check_exact_math(uint64_t * mismatches4);
 
+/* No counterpart in the reference: a self-check of the device's random number generator.  Runs the kernels'
+ * Philox4x32-10 on the device over the three known-answer inputs of the Random123 distribution (counter and key all
+ * zeros; all ones; digits of pi) -- words12 receives the three blocks of four words -- and over 2^20 further counters
+ * and keys, folded into one word (run_device); run_host receives the same fold computed on the host by the routine as
+ * published.  The device builds each 32 x 32 -> 64 bit product with one instruction through inline assembly;
+ * this is where that form is held against the known answers directly. */
+int rt_hip_check_philox(uint32_t * words12, uint32_t * run_device, uint32_t * run_host);
+
 /* Average device time (ms) of the trace kernel over `launches` back-to-back launches of the given frame on
  * the library's stream, measured with HIP events on that stream; used by the benchmark's roofline line. */
 int rt_hip_time_trace_kernel(const rt_hip_scene * scene, const rt_hip_camera * camera,

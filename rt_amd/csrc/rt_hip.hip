@@ -3184,6 +3184,100 @@ extern "C" int rt_hip_check_exact_math(uint64_t * mismatches4)
   return RT_HIP_OK;
 }
 
+namespace
+{
+// The device's Philox4x32-10 (rt_core.h philox4x32_10: both halves of each product from one v_mad_u64_u32) on three
+// known-answer inputs and, folded into one word by exclusive or, on a run of counters and keys.
+constexpr uint32_t kPhiloxRun = 1u << 20;
+__host__ __device__ inline void philox_run_input(uint32_t k, uint32_t (&in)[6])
+{
+  for (uint32_t j = 0; j < 6u; ++j)
+    in[j] = (k + j) * 0x9E3779B1u ^ ((k >> (j + 1u)) * 0x85EBCA77u) ^ (j * 0xC2B2AE3Du);
+}
+__host__ __device__ inline uint32_t philox_fold(u4 o) { return o.x ^ (o.y * 3u) ^ (o.z * 5u) ^ (o.w * 7u); }
+// Philox4x32-10 as published (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"), on the host.
+inline u4 philox_on_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+  for (int r = 0; r < 10; ++r)
+  {
+    unsigned long long const p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    uint32_t const n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  u4 o;
+  o.x = c0;
+  o.y = c1;
+  o.z = c2;
+  o.w = c3;
+  return o;
+}
+__global__ __launch_bounds__(256) void philox_check_kernel(uint32_t * out)
+{
+  uint32_t const t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 3u)
+  {
+    // the known-answer vectors of the Random123 distribution: zeros, ones, digits of pi
+    uint32_t const c[3][4] = {{0u, 0u, 0u, 0u}, {~0u, ~0u, ~0u, ~0u}, {0x243f6a88u, 0x85a308d3u, 0x13198a2eu, 0x03707344u}};
+    uint32_t const k[3][2] = {{0u, 0u}, {~0u, ~0u}, {0xa4093822u, 0x299f31d0u}};
+    u4 const o = philox4x32_10(c[t][0], c[t][1], c[t][2], c[t][3], k[t][0], k[t][1]);
+    out[4u * t + 0u] = o.x;
+    out[4u * t + 1u] = o.y;
+    out[4u * t + 2u] = o.z;
+    out[4u * t + 3u] = o.w;
+  }
+  uint32_t fold = 0u;
+  for (uint32_t i = t; i < kPhiloxRun; i += gridDim.x * blockDim.x)
+  {
+    uint32_t in[6];
+    philox_run_input(i, in);
+    fold ^= philox_fold(philox4x32_10(in[0], in[1], in[2], in[3], in[4], in[5]));
+  }
+  atomicXor(&out[12], fold);
+}
+}  // namespace
+
+extern "C" int rt_hip_check_philox(uint32_t * words12, uint32_t * run_device, uint32_t * run_host)
+{
+  if (!g_lib.ready)
+    return fail(RT_HIP_ERR_INVALID, "rt_hip_init has not been called");
+  if (words12 == nullptr || run_device == nullptr || run_host == nullptr)
+    return fail(RT_HIP_ERR_INVALID, "null argument");
+  uint32_t * d_out = nullptr;
+  RT_CHECK(hipMalloc((void **)&d_out, 13 * sizeof(uint32_t)));
+  hipError_t e = hipMemsetAsync(d_out, 0, 13 * sizeof(uint32_t), g_lib.stream);
+  if (e == hipSuccess)
+  {
+    hipLaunchKernelGGL(philox_check_kernel, dim3(64), dim3(256), 0, g_lib.stream, d_out);
+    e = hipGetLastError();
+  }
+  uint32_t host[13] = {0};
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(host, d_out, sizeof(host), hipMemcpyDeviceToHost, g_lib.stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(g_lib.stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERR_DEVICE, "rt_hip_check_philox", e);
+  for (int k = 0; k < 12; ++k)
+    words12[k] = host[k];
+  *run_device = host[12];
+  // the same run through the routine as published, on the host
+  uint32_t fold = 0u;
+  for (uint32_t i = 0; i < kPhiloxRun; ++i)
+  {
+    uint32_t in[6];
+    philox_run_input(i, in);
+    fold ^= philox_fold(philox_on_host(in[0], in[1], in[2], in[3], in[4], in[5]));
+  }
+  *run_host = fold;
+  return RT_HIP_OK;
+}
+
 #if defined(RT_PROFILE_REGIONS)
 // Profiling builds only: copies out and clears the per-wave timeline of the last resident-kernel launch
 // (four 100 MHz clock readings per wave: entry, staged, done, queue found used up).

@@ -128,6 +128,7 @@ HIP_SYMBOLS = {
         [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(Stats)],
     ),
     "rt_hip_check_exact_math": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "rt_hip_check_philox": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_hip_describe_launch": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(TraceParams), C.POINTER(LaunchInfo)]),
 }
 
@@ -394,6 +395,14 @@ class HipRenderer:
         out = (C.c_uint64 * 4)()
         self._check(self.lib.rt_hip_check_exact_math(out), "rt_hip_check_exact_math")
         return [int(v) for v in out]
+
+    def check_philox(self):
+        """The device's Philox4x32-10 on the Random123 known-answer inputs (three blocks of four words) and the fold
+        of a long run of blocks as the device and as the host computed it."""
+        words = (C.c_uint32 * 12)()
+        dev, host = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.rt_hip_check_philox(words, C.byref(dev), C.byref(host)), "rt_hip_check_philox")
+        return [int(w) for w in words], int(dev.value), int(host.value)
 
     def close(self):
         for handle, _ in self._scenes.values():

@@ -325,6 +325,16 @@ def test_short_exact_sequences_equal_the_compilers(hip):
     assert hip.check_exact_math() == [0, 0, 0, 0]
 
 
+def test_device_philox_against_the_known_answers(hip):
+    """The kernels' Philox4x32-10 takes both halves of each product from one v_mad_u64_u32 (inline assembly); the
+    device runs it on the Random123 known-answer inputs, and on a million further blocks against the host's form."""
+    words, run_device, run_host = hip.check_philox()
+    assert words[0:4] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert words[4:8] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert words[8:12] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert run_device == run_host
+
+
 def test_library_math_changes_no_bit(hip, ffi, scenes, monkeypatch):
     """RT_HIP_LIBRARY_MATH makes every exact intersection use the compiler's IEEE sequences: same frames, same
     counters, in deterministic and stochastic mode, brute force and grid."""
