@@ -14,6 +14,13 @@
 //   trace_kernel<*, true, *, false, true>  the kForward kernels once more, adding up the pixels themselves: a wave
 //                        keeps the column sums of its queue windows in LDS (PixelRing) and writes 12 bytes per pixel
 //                        when a window is done (RT_HIP_FLAG_KERNEL_SUMS; an option: these kernels run 3-5 % longer).
+//   trace_kernel<false, *, *, *, false, true>  the resident kernels once more, with the passes below moved to the end of
+//                        each wave's life: a wave notes its queue reservations in LDS (one word each; the loop is
+//                        otherwise untouched), and when it has no more work it completes its shared columns and adds
+//                        up the pixels of its own columns from the column sums it wrote (wave_sums).  What launches
+//                        that fill the chip use: no fold or accumulate launch between two frames of a stream.
+//   trace_kernel<true, true, *>  also hand the block's primary rays to its first lanes before a round over the
+//                        staged tiles (BlockEnv::gather_rays): a wave without a ray skips the round's arithmetic.
 //   fold_kernel          completes the sums of columns whose last samples were traced by other lanes of the
 //                        owner's wave (sample sharing at the end of the queue).
 //   trace_kernel<*, *, false, true>  the kernels for any number of lights built with the compiler's general IEEE
@@ -24,13 +31,16 @@
 //                        16 bytes per lane per access.  These are the HBM-bound passes.
 //   zero_kernel          clears a job's column sums (what a snapshot may read before the trace has written it).
 //   exact_math_check_kernel  self-check of the short correctly rounded sequences (rt_hip_check_exact_math).
+//   philox_check_kernel  the random number generator on known-answer inputs (rt_hip_check_philox).
 //
 //   camtab_kernel        per-launch set-up: table of the primary-ray filter (one entry per sphere), counters reset.
 //
 // LDS per block: the resident scene (56 B per sphere, 48 B per material and light) and 8 KB of prepared
 // columns, or one 20 KB staging tile for scenes above kResidentSpheres spheres; with RT_HIP_FLAG_KERNEL_SUMS also the
 // waves' rings (ring_bytes_per_wave: 0.4 KB + 768 B per window a wave may keep unfinished, as many as fit beside
-// the rest without costing a block per compute unit).
+// the rest without costing a block per compute unit); the kernels whose waves take the pixel sums at their end: 8 KB
+// of reservation logs in front of everything else (kLogBlockBytes); the tiled forward kernels: 7 KB for the exchange
+// of primary rays (RayExchange).
 #include "rt_core.h"
 #include "rt_hip.h"
 #include "rt_prep.h"
