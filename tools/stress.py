@@ -47,6 +47,9 @@ while time.time() < t_end:
             first[key] = out
         assert st.samples == w * h * s * s
     frames += 1
+    if frames % 5000 == 0:
+        # (a run that prints nothing for minutes is taken for hung)
+        print("%d frames so far, device memory drift %.1f MB" % (frames, (free0 - torch.cuda.mem_get_info()[0]) / 1e6), flush=True)
     if frames == 50:
         free0 = torch.cuda.mem_get_info()[0]
 free1 = torch.cuda.mem_get_info()[0]

@@ -101,6 +101,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "fuzz":
         a, sa = planes_of(scene, p, False)
         b, sb = planes_of(scene, p, True)
         n += 1
+        if n % 200 == 0:
+            print("%d frames so far" % n, flush=True)  # (a run that prints nothing for minutes is taken for hung)
         taken += took
         if not torch.equal(a, b) or sa[:4] != sb[:4]:
             print("DIFFER: %dx%d s=%d slice %d/%d %s" % (w, h, s, rank, world, "runs" if by_runs else "samples"))
