@@ -126,3 +126,39 @@ def test_gather_of_each_slices_runs_rebuilds_the_frame(hip, ffi, scenes):
     root = sharding.RunGather(n, world, 0, "cuda")
     root.unpack(slices[0], torch.stack(packed))  # what the gather delivers: world x 3 x count
     assert torch.equal(slices[0], whole)
+
+
+def test_the_launches_of_the_eight_rank_benchmark_gather_to_the_frame(hip, ffi, scenes):
+    """What each rank of `bench.py --gpus 8` launches -- its runs of the 1920x1080 16x16 frame as one of a stream of
+    frames, with block slots left free for the collective's kernels (RT_HIP_FLAG_PIPELINED | RT_HIP_FLAG_LEAVE_ROOM) --
+    and what the root makes of the ranks' packed runs: the one-GPU frame, bit for bit, counters summing to its
+    counters.  The launch is the one the slice timings quote: 960 blocks, pixel sums by the waves."""
+    import torch
+
+    from rt_amd import sharding
+
+    scene = scenes(1)
+    w, h, s, world = 1920, 1080, 16, 8
+    n = w * h
+    stream = torch.cuda.current_stream().cuda_stream
+    whole = torch.empty(3 * n, dtype=torch.float32, device="cuda")
+    whole_stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+    hip.trace_device(scene, ffi.params(w, h, s, seed=1), whole.data_ptr(), whole_stats.data_ptr(), stream)
+    flags = ffi.FLAG_PIPELINED | ffi.FLAG_LEAVE_ROOM
+    first, packed = None, []
+    counted = torch.zeros(4, dtype=torch.int64)
+    for rank in range(world):
+        p = sharding.slice_params(lambda: ffi.params(w, h, s, seed=1, flags=flags), rank, world, pixel_runs=True)
+        plan = hip.describe(scene, p)
+        assert (plan.blocks, plan.wave_sums, plan.kernel_sums) == (960, 1, 0)
+        planes = torch.full((3 * n,), float("nan"), dtype=torch.float32, device="cuda")
+        stats = torch.zeros(16, dtype=torch.int64, device="cuda")
+        hip.trace_device(scene, p, planes.data_ptr(), stats.data_ptr(), stream)
+        torch.cuda.synchronize()
+        counted += stats[:4].cpu()
+        packed.append(sharding.RunGather(n, world, rank, "cuda").pack(planes).clone())
+        if rank == 0:
+            first = planes
+    sharding.RunGather(n, world, 0, "cuda").unpack(first, torch.stack(packed))
+    assert torch.equal(first, whole)
+    assert counted.tolist() == whole_stats[:4].cpu().tolist()
