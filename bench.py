@@ -190,6 +190,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-reduce", action="store_true",
                     help="one frame at a time on one stream (default: two frames in flight on two streams)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="frames traced side by side (2 to 4), each on a stream with planes of its own (--sync-reduce: 1). "
+                         "One GPU, with the resolve pass behind every trace: 17.3 ms per frame with two, 17.5 with three or "
+                         "four; bare 1/8 slices on three streams of one priority ran 1.7 %% faster than on two "
+                         "(tools/streams_probe.py) -- for a first run on a node with several GPUs to try")
+    ap.add_argument("--equal-priorities", action="store_true",
+                    help="the frames' streams all take the default priority instead of two priorities in turn")
     ap.add_argument("--sample-slices", action="store_true",
                     help="several GPUs: divide the frame by samples (every rank visits every column) instead of by "
                          "runs of 64 pixels (a rank traces every sample of its pixels; the reduced frame then equals "
@@ -246,28 +253,28 @@ def main():
     # Two frames in flight, each with its own stream, sum planes, image and counters: frame k + 1 is traced while
     # the planes of frame k are still being reduced, and its first waves fill the compute units that the last
     # waves of frame k leave idle (rt_hip_trace_device keeps a workspace per stream).
-    lanes = 1 if args.sync_reduce else 2
-    # (different priorities: HIP then gives the streams hardware queues of their own, without which the second
-    # frame's kernels would simply queue behind the first's)
+    lanes = 1 if args.sync_reduce else max(2, min(args.frames_in_flight, 4))
+    sets = max(2, lanes)  # planes, image and counters per frame in flight (a frame's set belongs to its stream)
+    # (different priorities: HIP then gives the streams hardware queues of their own for certain)
     try:
-        streams = [torch.cuda.Stream(device=device, priority=-(i % 2)) for i in range(lanes)]
-    except (RuntimeError, ValueError):  # no stream priorities here: still correct, the frames just take turns
+        streams = [torch.cuda.Stream(device=device, priority=0 if args.equal_priorities else -(i % 2)) for i in range(lanes)]
+    except (RuntimeError, ValueError):  # no stream priorities here: still correct
         streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
-    planes = [torch.empty(3 * w * h, dtype=torch.float32, device=device) for _ in range(2)]
-    rgbs = [torch.empty(w * h * 3, dtype=torch.float32, device=device) for _ in range(2)] if rank == 0 else None
-    d_stats = [torch.zeros(16, dtype=torch.int64, device=device) for _ in range(2)]
+    planes = [torch.empty(3 * w * h, dtype=torch.float32, device=device) for _ in range(sets)]
+    rgbs = [torch.empty(w * h * 3, dtype=torch.float32, device=device) for _ in range(sets)] if rank == 0 else None
+    d_stats = [torch.zeros(16, dtype=torch.int64, device=device) for _ in range(sets)]
     renderer.upload(scene)
     rehearsing = args.rehearse and distributed
-    host = [torch.empty(3 * w * h, dtype=torch.float32) for _ in range(2)] if rehearsing else None
+    host = [torch.empty(3 * w * h, dtype=torch.float32) for _ in range(sets)] if rehearsing else None
 
     def on_stream(k):
         return torch.cuda.stream(streams[k % lanes])
 
     def resolve(k, summed):
         if rehearsing:
-            planes[k % 2].copy_(summed)
+            planes[k % sets].copy_(summed)
         stream = torch.cuda.current_stream().cuda_stream
-        renderer.resolve_device(planes[k % 2].data_ptr(), rgbs[k % 2].data_ptr(), full, stream)
+        renderer.resolve_device(planes[k % sets].data_ptr(), rgbs[k % sets].data_ptr(), full, stream)
 
     # slices by runs of pixels: every pixel comes from one rank, so the planes are put together by a gather of each
     # rank's own runs (1 / N of the bytes, nothing to add); slices by samples need the sum of the whole planes
@@ -300,9 +307,9 @@ def main():
         pipe.acquire(k)
         with on_stream(k):
             stream = torch.cuda.current_stream().cuda_stream
-            renderer.trace_device(scene, p, planes[k % 2].data_ptr(), d_stats[k % 2].data_ptr(), stream)
+            renderer.trace_device(scene, p, planes[k % sets].data_ptr(), d_stats[k % sets].data_ptr(), stream)
             if rehearsing:
-                host[k % 2].copy_(planes[k % 2])
+                host[k % sets].copy_(planes[k % sets])
             pipe.submit(k)
         if args.sync_reduce:
             pipe.drain()
@@ -542,11 +549,11 @@ def main():
                 "collective": collective,
             },
             "value_note": "throughput of a stream of frames, %d in flight, images left in HBM; the latency of one frame "
-                          "is ms_per_frame_one_at_a_time.  With two in flight the trace kernels of successive frames "
+                          "is ms_per_frame_one_at_a_time.  With several in flight the trace kernels of successive frames "
                           "run side by side for a while (kernels_in_stream, from the committed kernel trace of this "
                           "command): that is how a step can be shorter than the trace kernel launched alone "
                           "(roofline.kernel_ms)" % lanes,
-            "kernels_in_stream": overlap_profile(key) if lanes == 2 else None,
+            "kernels_in_stream": overlap_profile(key) if lanes == 2 and not args.equal_priorities else None,
             "ms_per_frame_one_at_a_time": round(single_ms, 3),
             "ms_per_frame_one_at_a_time_with_d2h": round(single_d2h_ms, 3),
             "ms_per_frame_with_d2h": round(stream_d2h_ms, 3) if stream_d2h_ms is not None else None,
