@@ -1350,6 +1350,15 @@ __global__ __launch_bounds__(kBlock, (kForward && !kTiled) ? kWavesPerSimdForwar
 #if defined(RT_PROFILE_REGIONS)
     timeline_mark(1);
 #endif
+    // The waves trace at wave priority 1 (a wave starts at 0).  Measured, not derived: set here -- after the tables are
+    // staged, in front of the loop -- every frame kind is 0.6-0.8 % faster, alone and in a stream of frames (1080p 16x16
+    // in a stream 17.31 -> 17.19 ms, glass 1024x768 32x32 26.44 -> 26.30, 10x10 2.81 -> 2.79), although all the waves
+    // of a launch and of the launch it overlaps sit at one priority either way; priority 3 gives the same.  Part of it
+    // is that nothing is scheduled across this instruction (the kernel with the reservation logs then spills 71 scalar
+    // registers instead of 77; a bare scheduling barrier here gives 0.16 %).  The same instruction at the top of the
+    // kernel costs 0.4 %, lowering the priority again for waves that have run out of work costs short frames 1 %, and
+    // raising only theirs costs long frames 0.3 %.
+    __builtin_amdgcn_s_setprio(1);
     WaveEnv<kLibMath, kFused, kLog> env{A, sph, cam, exact, mats, lights, smat, aux, jitter, batch + wave_in_block() * kItemBatch, ItemPool(), PixelRing()};
     if constexpr (kFused)
       env.ring.init(A, reinterpret_cast<unsigned char *>(batch + (kBlock / 64u) * kItemBatch) + wave_in_block() * ring_bytes_per_wave(A.ring_slots));
